@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Synthetic HMM generator: the build's counterpart of the reference's
+generate_data/data_script.py (same CLI flags, same file names, same text format,
+same distributions and the same numpy RNG call sequence, so the same seed gives
+byte-identical A_/B_/Pi_ files).
+
+Reference behaviour followed (file:line under /root/reference/generate_data/):
+  * transition matrix: data_script.py:5-35 — per source state, Binomial(K, p)
+    out-edges drawn without replacement, weights U(0.01, 1), row-normalised,
+    everything else exactly 0;
+  * emission matrix: data_script.py:38-49 — U(0.1, 1), row-normalised, the global
+    numpy RNG re-seeded with the same seed first;
+  * Pi = 1/K (:94); files and formats :98-101.
+
+Deliberate differences:
+  * the observation sequence is reproducible: the reference draws it from an
+    unseeded `random` (:86); here `random` is seeded with the -s seed (as the
+    reference's own data_script_dag.py:46 does) unless --ob-seed says otherwise;
+  * text is written by libfvhost (C) instead of np.savetxt — byte-identical
+    output, ~20x faster at K=3965 (a 299 MB file);
+  * --bin also writes raw float32 caches (`*.f32`, `ob_*.i32`) holding exactly
+    the floats the reference's fscanf("%f") loader would obtain from the text;
+  * -o chooses the output directory (the reference writes to the cwd).
+"""
+import getopt
+import os
+import random
+import sys
+
+import numpy as np
+
+USAGE = ("data_script.py -s <seed> -n <n_ob> -K <K> -T <T> -b <beam_width> -p <prob> "
+         "[-o <out_dir>] [--ob-seed <seed>] [--bin] [--no-text]")
+
+
+def make_transition(K, seed, prob):
+    """float64 K x K row-stochastic sparse-random transition matrix (data_script.py:5-35)."""
+    np.random.seed(seed)
+    A = np.zeros((K, K), dtype=np.float64)
+    for src in range(K):
+        n_edges = np.random.binomial(K, p=prob, size=None)
+        dst = np.random.choice(K, size=n_edges, replace=False)
+        w = np.random.uniform(0.01, 1, size=n_edges)
+        A[src, dst] = w
+    for src in range(K):
+        A[src, :] = A[src, :] / np.sum(A[src, :])
+    return A
+
+
+def make_emission(K, n_ob, seed):
+    """float64 K x n_ob row-stochastic emission matrix (data_script.py:38-49)."""
+    np.random.seed(seed)
+    B = np.random.uniform(0.1, 1, (K, n_ob))
+    return B / B.sum(axis=1)[:, None]
+
+
+def make_observations(T, n_ob, seed):
+    rng = random.Random(seed)
+    return [rng.randint(0, n_ob - 1) for _ in range(T)]
+
+
+def make_model64(K, n_ob, seed, prob):
+    """(A, B, Pi) in float64, exactly the arrays the reference generator saves."""
+    return make_transition(K, seed, prob), make_emission(K, n_ob, seed), np.full(K, 1 / K)
+
+
+def file_stem(kind, K, T, prob):
+    return f"{kind}_K{K}_T{T}_prob{prob}"
+
+
+def write_files(out_dir, K, T, prob, A, B, Pi, ob, text=True, binary=False):
+    from flash_viterbi_amd import hostio
+    os.makedirs(out_dir, exist_ok=True)
+    p = lambda kind, ext: os.path.join(out_dir, file_stem(kind, K, T, prob) + ext)
+    if text:
+        hostio.write_matrix_text16(p("A", ".txt"), A)
+        hostio.write_matrix_text16(p("B", ".txt"), B)
+        hostio.write_vector_text16(p("Pi", ".txt"), Pi)
+        hostio.write_ints_text(p("ob", ".txt"), ob)
+    if binary:
+        hostio.write_bin_f32(p("A", ".f32"), hostio.quantize_text16(A))
+        hostio.write_bin_f32(p("B", ".f32"), hostio.quantize_text16(B))
+        hostio.write_bin_f32(p("Pi", ".f32"), hostio.quantize_text16(Pi).reshape(1, -1))
+        hostio.write_bin_i32(p("ob", ".i32"), np.asarray(ob, dtype=np.int32).reshape(1, -1))
+
+
+def main(argv):
+    try:
+        opts, _ = getopt.getopt(argv, "hs:n:K:T:b:p:o:", ["ob-seed=", "bin", "no-text"])
+    except getopt.GetoptError:
+        print(USAGE)
+        sys.exit(2)
+    got = {}
+    out_dir, ob_seed, binary, text = ".", None, False, True
+    for opt, arg in opts:
+        if opt == "-h":
+            print(USAGE)
+            sys.exit()
+        elif opt in ("-s", "-n", "-K", "-T", "-b"):
+            got[opt] = int(arg)
+        elif opt == "-p":
+            got[opt] = float(arg)
+        elif opt == "-o":
+            out_dir = arg
+        elif opt == "--ob-seed":
+            ob_seed = int(arg)
+        elif opt == "--bin":
+            binary = True
+        elif opt == "--no-text":
+            text = False
+    if len(got) != 6:
+        print(USAGE)
+        sys.exit(2)
+    sd, n_ob, K, T, beam, prob = got["-s"], got["-n"], got["-K"], got["-T"], got["-b"], got["-p"]
+    os.makedirs(out_dir, exist_ok=True)
+    # the reference leaves a one-line stub behind (data_script.py:83-84); keep it so a
+    # directory produced here lists the same files
+    with open(os.path.join(out_dir, f"ANS_K{K}_T{T}_prob{prob}_beam_width{beam}.txt"), "w") as f:
+        f.write(f"sd={sd}, n_ob={n_ob}, K={K}, T={T}, beam_width={beam}, prob={prob}\n")
+    ob = make_observations(T, n_ob, sd if ob_seed is None else ob_seed)
+    A, B, Pi = make_model64(K, n_ob, sd, prob)
+    write_files(out_dir, K, T, prob, A, B, Pi, ob, text=text, binary=binary)
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    main(sys.argv[1:])

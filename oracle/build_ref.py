@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Compile the reference's own decoders into oracle/_ref/ (TEST INFRASTRUCTURE ONLY).
+
+The reference programs are configured at compile time (their `#define` block,
+reference src/FLASH_Viterbi_multithread.c:10-16, src/FLASH_BS_Viterbi_multithread.c:10-17).
+Its bench driver patches that block with regular expressions and runs gcc
+(reference src/run.py:29-54).  This script does the same thing, with two
+differences: the patched text is piped to gcc on stdin (no copy of the source
+is ever written anywhere) and the only output is the executable under
+oracle/_ref/ (git-ignored; it travels to the GPU box with the snapshot because
+/root/reference does not exist there).
+
+Every binary reads `{A,B,Pi,ob}_K{K}_T{T}_prob{p}.txt` from its current working
+directory (data_path is patched to "./") and prints the reference's three
+stdout lines.  With score=True one fprintf(stderr) of the whole-sequence
+pass's final score is spliced in after the end-state argmax; nothing else changes.
+"""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(HERE, "_ref")
+
+SOURCES = {"flash": "FLASH_Viterbi_multithread.c", "flashbs": "FLASH_BS_Viterbi_multithread.c"}
+# gcc flags exactly as reference src/run.py:54
+GCC = ["gcc", "-g", "-pthread", "-x", "c", "-", "-lm", "-Wl,-z,stack-size=268435456"]
+
+
+def ref_name(kind, K, T, prob, N, beam=None, M=50, score=False):
+    s = f"{kind}_K{K}_T{T}_p{prob}_N{N}"
+    if kind == "flashbs":
+        s += f"_B{beam}"
+    if M != 50:
+        s += f"_M{M}"
+    if score:
+        s += "_score"
+    return s
+
+
+def reference_available():
+    return all(os.path.isfile(os.path.join(REF_SRC, f)) for f in SOURCES.values())
+
+
+def _patch(text, kind, K, T, prob, N, beam, M, score):
+    def sub1(pat, repl, s):
+        out, n = re.subn(pat, repl, s)
+        if n < 1:
+            raise RuntimeError(f"pattern not found in reference source: {pat}")
+        return out
+    text = sub1(r"#define K_STATE \d+", f"#define K_STATE {K}", text)
+    text = sub1(r"#define T_STATE \d+", f"#define T_STATE {M}", text)
+    text = sub1(r"#define obserRouteLEN \d+", f"#define obserRouteLEN {T}", text)
+    text = sub1(r"const float prob = \d+\.\d+;", f"const float prob = {prob};", text)
+    text = sub1(r'const char data_path\[\] = "[^"]*";', 'const char data_path[] = "./";', text)
+    text = sub1(r"#define MAX_THREADS \d+", f"#define MAX_THREADS {N}", text)
+    if kind == "flashbs":
+        text = sub1(r"const int BeamSearchWidth = \d+;", f"const int BeamSearchWidth = {beam};", text)
+    digits = len(str(prob).split(".")[1]) if "." in str(prob) else 0
+    text = sub1(r"prob%\.\d+f", f"prob%.{digits}f", text)
+    if score:
+        # after the whole-sequence end-state pick ("vit->Ans[R] = arg;" / "... .State;")
+        if kind == "flash":
+            text = sub1(r"(vit->Ans\[R\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)score);', text)
+        else:
+            text = sub1(r"(vit->Ans\[R\] = H\[cur\](?:\[1\])?\[arg\+1\]\.State;)",
+                        r'\1 fprintf(stderr, "score: %.9g\\n", (double)score);', text)
+    return text
+
+
+def build(kind, K, T, prob, N, beam=None, M=50, score=False, force=False):
+    """Returns the path of the binary, building it if the reference tree is present.
+    Raises FileNotFoundError when neither the binary nor the reference exists."""
+    os.makedirs(OUT, exist_ok=True)
+    exe = os.path.join(OUT, ref_name(kind, K, T, prob, N, beam, M, score))
+    if os.path.isfile(exe) and not force:
+        return exe
+    if not reference_available():
+        raise FileNotFoundError(f"{exe} not prebuilt and {REF_SRC} is absent")
+    with open(os.path.join(REF_SRC, SOURCES[kind]), "r") as f:
+        text = _patch(f.read(), kind, K, T, prob, N, beam, M, score)
+    res = subprocess.run(GCC + ["-o", exe], input=text, text=True, capture_output=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"gcc failed for {exe}:\n{res.stderr}")
+    return exe
+
+
+def run(exe, data_dir, timeout=3600):
+    """Runs a reference binary in data_dir; returns dict(time, path, memory, score)."""
+    res = subprocess.run([exe], cwd=data_dir, capture_output=True, text=True, timeout=timeout)
+    if res.returncode != 0:
+        raise RuntimeError(f"{exe} exited {res.returncode}: {res.stderr[-400:]}")
+    out = res.stdout
+    t = float(re.search(r"time: ([\d.]+)", out).group(1))          # reference run.py:75
+    mem = int(re.search(r"memory: (-?\d+)", out).group(1))        # reference run.py:76
+    path = [int(x) for x in re.search(r"path: \[([^\]]*)\]", out).group(1).split()]
+    ms = re.search(r"score: (\S+)", res.stderr)
+    return {"time": t, "memory": mem, "path": path, "score": float(ms.group(1)) if ms else None}
+
+
+# Binaries that must exist on the GPU box (no reference tree there): the bench's
+# cpu_baseline sample.  Golden-vector binaries are built on demand by
+# tests/golden/make_golden.py.
+DEFAULT_SET = [
+    dict(kind="flash", K=3965, T=64, prob=0.112, N=8),
+]
+
+if __name__ == "__main__":
+    if not reference_available():
+        print("build_ref: /root/reference absent; keeping prebuilt oracle/_ref as is")
+        sys.exit(0)
+    for cfg in DEFAULT_SET:
+        print(build(**cfg))

@@ -1,0 +1,77 @@
+"""Test-side model builders: every golden case is described by a small spec dict
+from which the float64 model the generator would have saved is rebuilt, then
+pushed through the text quantisation the reference loader applies."""
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flash_viterbi_amd import hostio  # noqa: E402
+from flash_viterbi_amd.generate_data import data_script  # noqa: E402
+
+
+def _ties_all(K, M, seed, degree=8):
+    """Every row has `degree` out-edges of weight 1/degree, B and Pi uniform: every finite
+    score at a step is the same float, so the decoded path is decided by tie-breaking only."""
+    rs = np.random.RandomState(seed)
+    A = np.zeros((K, K))
+    for k in range(K):
+        A[k, rs.choice(K, size=degree, replace=False)] = 1.0 / degree
+    return A, np.full((K, M), 1.0 / M), np.full(K, 1.0 / K)
+
+
+def _ties_semi(K, M, seed):
+    """Dyadic weights (row sums exactly 1): many, but not all, candidates tie."""
+    rs = np.random.RandomState(seed)
+    A = np.zeros((K, K))
+    w = np.array([0.25, 0.25, 0.125, 0.125, 0.125, 0.125])
+    for k in range(K):
+        A[k, rs.choice(K, size=w.size, replace=False)] = rs.permutation(w)
+    base = np.array([0.5, 0.25, 0.125, 0.125] + [0.0] * (M - 4)) if M >= 4 else np.full(M, 1.0 / M)
+    if M > 4:  # keep every symbol possible: split the last weight
+        base = np.array([0.5, 0.25, 0.125] + [0.125 / (M - 3)] * (M - 3))
+    B = np.stack([rs.permutation(base) for _ in range(K)])
+    return A, B, np.full(K, 1.0 / K)
+
+
+def model64(spec):
+    kind = spec["kind"]
+    K, M = spec["K"], spec["M"]
+    if kind == "data_script":
+        return data_script.make_model64(K, M, spec["seed"], spec["prob"])
+    if kind == "ties_all":
+        return _ties_all(K, M, spec["seed"])
+    if kind == "ties_semi":
+        return _ties_semi(K, M, spec["seed"])
+    raise ValueError(kind)
+
+
+def observations(spec):
+    if "ob" in spec:
+        return np.asarray(spec["ob"], dtype=np.int32)
+    rng = random.Random(spec.get("ob_seed", spec["seed"]))
+    return np.asarray([rng.randint(0, spec["M"] - 1) for _ in range(spec["T"])], dtype=np.int32)
+
+
+def model32(spec):
+    """(A, B, Pi, ob) in the float32 the reference loader reads from the generator's text."""
+    A, B, Pi = model64(spec)
+    return (hostio.quantize_text16(A), hostio.quantize_text16(B), hostio.quantize_text16(Pi),
+            observations(spec))
+
+
+def write_text(spec, out_dir):
+    """Writes the four text files the reference programs open (prob is part of the name)."""
+    A, B, Pi = model64(spec)
+    data_script.write_files(out_dir, spec["K"], spec["T"], spec["prob"], A, B, Pi,
+                            observations(spec), text=True, binary=False)
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

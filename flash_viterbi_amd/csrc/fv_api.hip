@@ -1,0 +1,580 @@
+// fv_api.hip — the C-ABI of include/flashvit.h over the gfx950 kernels.
+//
+// Everything a decode needs is enqueued on one HIP stream without a single host
+// round trip: the task tree depends only on (T, n_split), and every state index a
+// later pass consumes (Ans[L-1], Ans[R]) stays in device memory.  One sync at the end.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "flashvit.h"
+#include "fv_schedule.h"
+#include "fv_kernels.hip.inc"
+#include "fv_beam_kernels.hip.inc"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t want)
+    {
+        if (want <= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc(&p, want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+}  // namespace
+
+struct fv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr;
+    std::string detail;
+
+    // model
+    int K = 0, M = 0, nrows = 0, rows_alloc = 0;
+    long long pitch = 0;
+    bool logs_nonpositive = false;
+    DevBuf<float> LA32, LB32T;
+    DevBuf<double> LA64, LB64T, LPi64;
+
+    // workspace
+    DevBuf<int> d_ob, d_ans, d_bp, d_gather;
+    DevBuf<float> d_rows, d_score;
+    DevBuf<unsigned long long> d_counters;
+    // beam workspace
+    DevBuf<float> d_hval, d_scores;
+    DevBuf<int> d_hstate, d_flags;
+
+    // options
+    int opt_kernel = FV_KERNEL_AUTO;
+    int opt_max_batch = fvk::MAX_BATCH;
+    int opt_profile = 0;
+    std::vector<hipEvent_t> prof_events;
+
+    // comm
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    fv_stats stats{};
+};
+
+namespace {
+
+#define FV_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ctx->detail = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? FV_ERR_NOMEM : FV_ERR_DEVICE;                  \
+        }                                                                                     \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+size_t device_bytes(const fv_ctx *c)
+{
+    return c->LA32.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
+           c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
+           c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
+           c->d_hstate.bytes() + c->d_flags.bytes();
+}
+
+// log() of a strided block of floats on several host threads (same libm call per entry as the reference).
+template <typename F>
+void parallel_rows(int rows, F &&fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<unsigned>(hw ? hw : 4, 16);
+    if (rows < 256) nt = 1;
+    if (nt <= 1) { fn(0, rows); return; }
+    std::vector<std::thread> th;
+    int per = (rows + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        int a = t * per, b = std::min(rows, a + per);
+        if (a >= b) break;
+        th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
+
+int pick_kernel(const fv_ctx *ctx)
+{
+    if (ctx->opt_kernel == FV_KERNEL_F64_STREAM) return FV_KERNEL_F64_STREAM;
+    // F32_REFINE's 2-ulp bracket needs every log <= 0 (no cancellation between score and log A)
+    return ctx->logs_nonpositive ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
+}
+
+template <typename TA, int NB>
+int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32)
+{
+    fvk::StepArgs<NB> a;
+    a.LA = f32 ? (const void *)ctx->LA32.p : (const void *)ctx->LA64.p;
+    a.LA64 = ctx->LA64.p;
+    a.LB32T = ctx->LB32T.p;
+    a.ob = ctx->d_ob.p;
+    a.counters = ctx->d_counters.p;
+    a.pitch = ctx->pitch;
+    a.K = ctx->K;
+    a.nrows = ctx->nrows;
+    a.ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    a.nb = nb;
+    for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
+    const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
+    hipLaunchKernelGGL((fvk::trellis_step<TA, NB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename TA>
+int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32)
+{
+    if (nb <= 1) return launch_step_nb<TA, 1>(ctx, slots, nb, f32);
+    if (nb <= 2) return launch_step_nb<TA, 2>(ctx, slots, nb, f32);
+    if (nb <= 4) return launch_step_nb<TA, 4>(ctx, slots, nb, f32);
+    return launch_step_nb<TA, 8>(ctx, slots, nb, f32);
+}
+
+template <typename TA, int NB>
+int allow_big_lds(fv_ctx *ctx)
+{
+    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+// largest batch whose score rows fit LDS next to the reduction scratch
+int max_batch_for(int nrows)
+{
+    int nb = fvk::MAX_BATCH;
+    while (nb > 1) {
+        size_t need = nb == 8 ? fvk::step_lds_bytes<8>(nrows) : nb == 4 ? fvk::step_lds_bytes<4>(nrows)
+                                                                        : fvk::step_lds_bytes<2>(nrows);
+        if (need <= 160 * 1024) break;
+        nb >>= 1;
+    }
+    return nb;
+}
+
+int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
+{
+    FV_HIP(ctx->d_ob.ensure(T));
+    FV_HIP(ctx->d_ans.ensure(T));
+    FV_HIP(ctx->d_bp.ensure((size_t)T * ctx->K));
+    FV_HIP(ctx->d_rows.ensure(rows_needed * 2 * ctx->K));
+    FV_HIP(ctx->d_score.ensure(4));
+    FV_HIP(ctx->d_counters.ensure(4));
+    if (ctx->nranks > 1) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
+    return 0;
+}
+
+struct ProfRange { size_t first, count; };
+
+int prof_event(fv_ctx *ctx, size_t idx, hipEvent_t *out)
+{
+    while (ctx->prof_events.size() <= idx) {
+        hipEvent_t e;
+        FV_HIP(hipEventCreate(&e));
+        ctx->prof_events.push_back(e);
+    }
+    *out = ctx->prof_events[idx];
+    return 0;
+}
+
+// Runs every pass of one generation in lock-step: at lock-step s each still-active pass advances
+// from time L+s-1 to L+s.  Passes are sorted longest first so the active set is a prefix.
+int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, size_t &nprof)
+{
+    const int K = ctx->K;
+    const int np = (int)passes.size();
+    if (np == 0) return 0;
+    std::stable_sort(passes.begin(), passes.end(),
+                     [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
+    // init rows
+    for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
+        fvk::PassChunk ch;
+        ch.n = std::min(fvk::PASS_CHUNK, np - base);
+        for (int q = 0; q < ch.n; ++q) {
+            const fv::Pass &p = passes[base + q];
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * K };
+        }
+        hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
+                           ctx->LA64.p, ctx->pitch, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
+                           ctx->d_rows.p, K);
+        FV_HIP(hipGetLastError());
+    }
+    const int maxlen = passes[0].R - passes[0].L;
+    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows)));
+    int active = np;
+    for (int s = 1; s <= maxlen; ++s) {
+        while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
+        for (int base = 0; base < active; base += cap) {
+            const int nb = std::min(cap, active - base);
+            fvk::TaskSlot slots[fvk::MAX_BATCH];
+            for (int q = 0; q < nb; ++q) {
+                const fv::Pass &p = passes[base + q];
+                float *r0 = ctx->d_rows.p + (size_t)(base + q) * 2 * K;
+                slots[q].t1_in = r0 + (size_t)((s - 1) & 1) * K;
+                slots[q].t1_out = r0 + (size_t)(s & 1) * K;
+                slots[q].j = p.L + s;
+                slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
+            }
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ctx->opt_profile) {
+                int rc = prof_event(ctx, nprof, &e0); if (rc) return rc;
+                rc = prof_event(ctx, nprof + 1, &e1); if (rc) return rc;
+                nprof += 2;
+                FV_HIP(hipEventRecord(e0, ctx->stream));
+            }
+            int rc = f32 ? launch_step<float>(ctx, slots, nb, true) : launch_step<double>(ctx, slots, nb, false);
+            if (rc) return rc;
+            if (ctx->opt_profile) FV_HIP(hipEventRecord(e1, ctx->stream));
+            ctx->stats.step_launches += 1;
+            ctx->stats.task_steps += nb;
+        }
+    }
+    // end states + chains
+    for (int q = 0; q < np; ++q) {
+        if (!passes[q].whole) continue;
+        const int len = passes[q].R - passes[q].L;
+        const float *last = ctx->d_rows.p + (size_t)q * 2 * K + (size_t)(len & 1) * K;
+        hipLaunchKernelGGL(fvk::final_argmax, dim3(1), dim3(1024), 0, ctx->stream, last, K,
+                           ctx->d_ans.p + passes[q].R, ctx->d_score.p);
+        FV_HIP(hipGetLastError());
+    }
+    for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
+        fvk::PassChunk ch;
+        ch.n = std::min(fvk::PASS_CHUNK, np - base);
+        for (int q = 0; q < ch.n; ++q) {
+            const fv::Pass &p = passes[base + q];
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, 0 };
+        }
+        hipLaunchKernelGGL(fvk::backtrack, dim3(ch.n), dim3(64), 0, ctx->stream, ch, ctx->d_bp.p, K, ctx->d_ans.p);
+        FV_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// Merge of the per-rank answer arrays after the all-gather: position j is taken from the rank that
+// owns the top-level segment containing it (segment end points are fixed by the whole-sequence
+// pass, identical on every rank).
+void merge_gathered(const fv::Plan &plan, const std::vector<int> &gathered, int T, int nranks, int *path)
+{
+    for (int j = 0; j < T; ++j) path[j] = gathered[j];   // rank 0's copy: whole-pass values
+    for (size_t s = 0; s < plan.seg_L.size(); ++s) {
+        const int r = plan.seg_owner[s] % nranks;
+        for (int j = plan.seg_L[s]; j < plan.seg_R[s]; ++j) path[j] = gathered[(size_t)r * T + j];
+    }
+}
+
+int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float *score_out, clk::time_point t0,
+                  size_t nprof, bool beam)
+{
+    std::vector<int> host;
+    if (ctx->nranks > 1 && !plan.seg_L.empty()) {
+        ncclResult_t nr = ncclAllGather(ctx->d_ans.p, ctx->d_gather.p, (size_t)T, ncclInt32, ctx->comm, ctx->stream);
+        if (nr != ncclSuccess) { ctx->detail = std::string("ncclAllGather: ") + ncclGetErrorString(nr); return FV_ERR_COMM; }
+        host.resize((size_t)T * ctx->nranks);
+        FV_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+        FV_HIP(hipMemcpyAsync(host.data(), ctx->d_gather.p, host.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        FV_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+        FV_HIP(hipMemcpyAsync(path_out, ctx->d_ans.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    float score = 0.f;
+    unsigned long long counters[4] = { 0, 0, 0, 0 };
+    FV_HIP(hipMemcpyAsync(&score, ctx->d_score.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(hipMemcpyAsync(counters, ctx->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(hipStreamSynchronize(ctx->stream));
+    if (!host.empty()) merge_gathered(plan, host, T, ctx->nranks, path_out);
+    if (score_out) *score_out = score;
+
+    fv_stats &st = ctx->stats;
+    st.decode_ms = ms_since(t0);
+    float ms = 0.f;
+    FV_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop)); st.gpu_ms = ms;
+    FV_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_top)); st.top_pass_ms = ms;
+    st.step_kernel_ms = 0;
+    for (size_t i = 0; i + 1 < nprof; i += 2) {
+        FV_HIP(hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        st.step_kernel_ms += ms;
+    }
+    st.refine_near = (long long)counters[0];
+    st.refine_rescan = (long long)counters[1];
+    st.device_bytes = (long long)device_bytes(ctx);
+    st.ranks = ctx->nranks;
+    bool neg = false;
+    for (int j = 0; j < T; ++j) neg |= path_out[j] < 0;
+    if (neg) return beam ? FV_WARN_BEAM_MISS : FV_ERR_NO_PRED;
+    return FV_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" int fv_create(fv_ctx **out, int device)
+{
+    if (!out) return FV_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FV_ERR_DEVICE;
+    fv_ctx *ctx = new (std::nothrow) fv_ctx();
+    if (!ctx) return FV_ERR_NOMEM;
+    ctx->device = device;
+    auto fail = [&](int rc) { fv_destroy(ctx); return rc; };
+    if (hipSetDevice(device) != hipSuccess) return fail(FV_ERR_DEVICE);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(FV_ERR_DEVICE);
+    if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        hipEventCreate(&ctx->ev_top) != hipSuccess)
+        return fail(FV_ERR_DEVICE);
+    int rc = 0;
+    if ((rc = allow_big_lds<float, 1>(ctx)) || (rc = allow_big_lds<float, 2>(ctx)) || (rc = allow_big_lds<float, 4>(ctx)) ||
+        (rc = allow_big_lds<float, 8>(ctx)) || (rc = allow_big_lds<double, 1>(ctx)) || (rc = allow_big_lds<double, 2>(ctx)) ||
+        (rc = allow_big_lds<double, 4>(ctx)) || (rc = allow_big_lds<double, 8>(ctx)))
+        return fail(rc);
+    if ((rc = fvb::allow_big_lds(ctx->detail))) return fail(rc);
+    *out = ctx;
+    return FV_OK;
+}
+
+extern "C" void fv_destroy(fv_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) ncclCommDestroy(ctx->comm);
+    ctx->LA32.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
+    ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
+    ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
+    ctx->d_hstate.release(); ctx->d_flags.release();
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_top) (void)hipEventDestroy(ctx->ev_top);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const float *Pi, int K, int M)
+{
+    if (!ctx || !A || !B || !Pi || K < 1 || M < 1) return FV_ERR_ARG;
+    auto t0 = clk::now();
+    FV_HIP(hipSetDevice(ctx->device));
+    const int nrows = round_up(K, fvk::ROWS_PER_IT);
+    const int rows_alloc = nrows + fvk::ROWS_PER_IT;       // at least one full block of -inf rows
+    const long long pitch = nrows;
+    if (fvk::step_lds_bytes<1>(nrows) > 160 * 1024) return FV_ERR_UNSUPPORTED;   // one score row must fit LDS
+
+    const size_t tab = (size_t)rows_alloc * pitch;
+    std::vector<double> h64;
+    std::vector<float> h32;
+    try { h64.assign(tab, -HUGE_VAL); h32.assign(tab, -HUGE_VALF); } catch (...) { return FV_ERR_NOMEM; }
+    bool ok_range = true;
+    std::vector<char> bad(K, 0), big(K, 0);
+    parallel_rows(K, [&](int a, int b) {
+        for (int k = a; k < b; ++k) {
+            const float *src = A + (size_t)k * K;
+            double *d = h64.data() + (size_t)k * pitch;
+            float *f = h32.data() + (size_t)k * pitch;
+            for (int i = 0; i < K; ++i) {
+                const float x = src[i];
+                if (!(x >= 0.0f) || std::isinf(x)) bad[k] = 1;
+                if (x > 1.0f) big[k] = 1;
+                const double l = std::log((double)x);
+                d[i] = l; f[i] = (float)l;
+            }
+        }
+    });
+    std::vector<double> b64((size_t)M * K), pi64(K);
+    std::vector<float> b32((size_t)M * K);
+    for (int i = 0; i < K; ++i) {
+        for (int o = 0; o < M; ++o) {
+            const float x = B[(size_t)i * M + o];
+            if (!(x >= 0.0f) || std::isinf(x)) ok_range = false;
+            if (x > 1.0f) big[0] = 1;
+            const double l = std::log((double)x);
+            b64[(size_t)o * K + i] = l; b32[(size_t)o * K + i] = (float)l;
+        }
+        const float x = Pi[i];
+        if (!(x >= 0.0f) || std::isinf(x)) ok_range = false;
+        if (x > 1.0f) big[0] = 1;
+        pi64[i] = std::log((double)x);
+    }
+    bool any_big = false;
+    for (int k = 0; k < K; ++k) { if (bad[k]) ok_range = false; if (big[k]) any_big = true; }
+    if (!ok_range) { ctx->detail = "model entries must be finite and >= 0"; return FV_ERR_ARG; }
+
+    FV_HIP(ctx->LA64.ensure(tab));
+    FV_HIP(ctx->LA32.ensure(tab));
+    FV_HIP(ctx->LB64T.ensure((size_t)M * K));
+    FV_HIP(ctx->LB32T.ensure((size_t)M * K));
+    FV_HIP(ctx->LPi64.ensure(K));
+    FV_HIP(hipMemcpy(ctx->LA64.p, h64.data(), tab * sizeof(double), hipMemcpyHostToDevice));
+    FV_HIP(hipMemcpy(ctx->LA32.p, h32.data(), tab * sizeof(float), hipMemcpyHostToDevice));
+    FV_HIP(hipMemcpy(ctx->LB64T.p, b64.data(), b64.size() * sizeof(double), hipMemcpyHostToDevice));
+    FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
+    FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->rows_alloc = rows_alloc; ctx->pitch = pitch;
+    ctx->logs_nonpositive = !any_big;
+    ctx->stats = fv_stats{};
+    ctx->stats.set_model_ms = ms_since(t0);
+    ctx->stats.device_bytes = (long long)device_bytes(ctx);
+    return FV_OK;
+}
+
+extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
+{
+    if (!ctx) return FV_ERR_ARG;
+    switch (key) {
+    case FV_OPT_KERNEL:
+        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_F32_REFINE) return FV_ERR_ARG;
+        ctx->opt_kernel = (int)value; return FV_OK;
+    case FV_OPT_MAX_BATCH:
+        if (value < 1 || value > fvk::MAX_BATCH) return FV_ERR_ARG;
+        ctx->opt_max_batch = (int)value; return FV_OK;
+    case FV_OPT_PROFILE:
+        ctx->opt_profile = value ? 1 : 0; return FV_OK;
+    default: return FV_ERR_ARG;
+    }
+}
+
+extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, int *path_out, float *score_out)
+{
+    if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
+    if (ctx->K == 0) return FV_ERR_STATE;
+    for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
+    if (ctx->opt_kernel == FV_KERNEL_F32_REFINE && !ctx->logs_nonpositive) {
+        ctx->detail = "FV_KERNEL_F32_REFINE needs every model entry in [0,1]";
+        return FV_ERR_UNSUPPORTED;
+    }
+    auto t0 = clk::now();
+    FV_HIP(hipSetDevice(ctx->device));
+    fv::Plan plan;
+    int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
+    if (rc) return rc;
+    const bool f32 = pick_kernel(ctx) == FV_KERNEL_F32_REFINE;
+
+    // generations of passes this rank runs
+    std::vector<std::vector<fv::Pass>> gens(plan.generations());
+    size_t most = 1;
+    for (const fv::Pass &p : plan.passes)
+        if (p.owner < 0 || p.owner % ctx->nranks == ctx->rank) gens[p.generation].push_back(p);
+    for (auto &g : gens) most = std::max(most, g.size());
+    if ((rc = ensure_workspace(ctx, T, most))) return rc;
+
+    const double keep_model_ms = ctx->stats.set_model_ms;
+    ctx->stats = fv_stats{};
+    ctx->stats.set_model_ms = keep_model_ms;
+    ctx->stats.kernel = f32 ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
+    ctx->stats.generations = plan.generations();
+    ctx->stats.table_bytes_per_step = (long long)ctx->nrows * ctx->pitch * (f32 ? 4 : 8);
+
+    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ob, (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    size_t nprof = 0;
+    for (size_t g = 0; g < gens.size(); ++g) {
+        ctx->stats.passes += (int)gens[g].size();
+        if ((rc = run_generation_full(ctx, gens[g], f32, nprof))) return rc;
+        if (g == 0) FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream));
+    }
+    ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * ctx->K;
+    ctx->stats.alg_bytes = 4 * ctx->stats.cells;
+    return finish_decode(ctx, plan, T, path_out, score_out, t0, nprof, false);
+}
+
+extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode,
+                              int *path_out, float *score_out)
+{
+    (void)ctx; (void)ob; (void)T; (void)n_split; (void)beam_width; (void)mode; (void)path_out; (void)score_out;
+    return FV_ERR_UNSUPPORTED;
+}
+
+extern "C" int fv_last_stats(const fv_ctx *ctx, fv_stats *out)
+{
+    if (!ctx || !out) return FV_ERR_ARG;
+    *out = ctx->stats;
+    return FV_OK;
+}
+
+extern "C" const char *fv_last_error_detail(const fv_ctx *ctx) { return ctx ? ctx->detail.c_str() : ""; }
+
+extern "C" const char *fv_strerror(int rc)
+{
+    switch (rc) {
+    case FV_OK: return "ok";
+    case FV_WARN_BEAM_MISS: return "beam miss: path holds -1 entries, as the reference prints";
+    case FV_ERR_ARG: return "bad argument";
+    case FV_ERR_NOMEM: return "out of memory";
+    case FV_ERR_NO_PRED: return "decoded entry has no finite predecessor";
+    case FV_ERR_DEVICE: return "HIP error";
+    case FV_ERR_STATE: return "call out of order (no model / no communicator)";
+    case FV_ERR_UNSUPPORTED: return "size or option not supported by this build";
+    case FV_ERR_COMM: return "RCCL error";
+    default: return "unknown flashvit error";
+    }
+}
+
+extern "C" long long fv_reference_memory_bytes(int K, int T, int n_split, int beam_width)
+{
+    // sizeof(ThreadPool) on x86-64 glibc: mutex 40 + cond 48 + N pthread_t + 3 ints, padded to 8
+    const long long N = n_split;
+    const long long pool = ((40 + 48 + 8 * N + 12 + 7) / 8) * 8;
+    long long mem = 0, tmp;
+    const bool nway = N > 2 && T >= 2 * N;
+    if (beam_width <= 0) {
+        if (nway) mem = 4 * (N - 1) + 2LL * K * 4 + 2 * (N - 1) * (long long)K * 4;    // FLASH:355
+        tmp = N * (2LL * K * 4 + 2LL * K * 4);                                         // :364
+    } else {
+        if (nway) mem = 4 * (N - 1) + 2 * (N - 1) * (long long)(beam_width + 1) * 12;  // FLASH_BS:564
+        tmp = N * (2LL * (beam_width + 1) * 12);                                       // :573
+    }
+    if (tmp > mem) mem = tmp;
+    return mem + pool + 8;     // + sizeof(ThreadPool) + sizeof(size_t) (the sizeof(expr) quirk, FLASH:367)
+}
+
+extern "C" int fv_comm_unique_id(void *id_out)
+{
+    if (!id_out) return FV_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) <= FV_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return FV_ERR_COMM;
+    std::memset(id_out, 0, FV_UNIQUE_ID_BYTES);
+    std::memcpy(id_out, &id, sizeof id);
+    return FV_OK;
+}
+
+extern "C" int fv_comm_init(fv_ctx *ctx, int rank, int nranks, const void *id)
+{
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return FV_ERR_ARG;
+    if (ctx->comm) return FV_ERR_STATE;
+    FV_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclResult_t nr = ncclCommInitRank(&ctx->comm, nranks, uid, rank);
+    if (nr != ncclSuccess) { ctx->detail = std::string("ncclCommInitRank: ") + ncclGetErrorString(nr); ctx->comm = nullptr; return FV_ERR_COMM; }
+    ctx->rank = rank; ctx->nranks = nranks;
+    return FV_OK;
+}

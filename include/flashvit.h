@@ -1,0 +1,135 @@
+/*
+ * flashvit.h — C ABI of libflashvit.so, the MI355X (gfx950) implementation of the
+ * FLASH / FLASH-BS Viterbi hot path.  extern "C", plain pointers and sizes only.
+ *
+ * The reference has no library API: its seam is `void calc(void)` over the globals
+ * `VIT *vit; ThreadPool pool;` (reference src/FLASH_Viterbi_multithread.c:45-46,338-368;
+ * src/FLASH_BS_Viterbi_multithread.c:47-48,548-577), called once from main() inside
+ * the clock_gettime bracket (:375-377).  Each entry point below names the piece of
+ * that seam it replaces.  Caller owns every host buffer passed in or out; the
+ * library never frees caller memory; one ctx is not thread-safe; functions return
+ * 0 on success, >0 for warnings that still deliver the reference's result, <0 for
+ * errors (never abort, never perror-and-continue as the reference's loader does).
+ */
+#ifndef FLASHVIT_H
+#define FLASHVIT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fv_ctx fv_ctx;
+
+enum {
+    FV_OK = 0,
+    /* Find_T3_State returned -1 in some task (FLASH_BS:73-86,466-471): the path holds -1
+     * entries and later tasks restart from Pi, exactly what the reference binary prints. */
+    FV_WARN_BEAM_MISS = 1,
+    FV_ERR_ARG = -1,         /* bad pointer / size; T == 2*n_split with n_split > 2 */
+    FV_ERR_NOMEM = -2,       /* host or device allocation failed */
+    FV_ERR_NO_PRED = -3,     /* a decoded entry has no finite predecessor (reference: T2[cur][-1], UB) */
+    FV_ERR_DEVICE = -4,      /* a HIP call failed; fv_last_error_detail() has the text */
+    FV_ERR_STATE = -5,       /* decode before fv_set_model, comm calls out of order */
+    FV_ERR_UNSUPPORTED = -6, /* size outside what the kernels are built for */
+    FV_ERR_COMM = -7,        /* RCCL failure */
+};
+
+/* `mode` argument of the decode calls. */
+enum {
+    /* Replays the reference's divide-and-conquer task tree pass for pass (top-level N-way
+     * pass, then every bisection task whose rounding history differs from its parent's),
+     * so every float the reference compares is reproduced: bit-exact paths by construction. */
+    FV_MODE_REFERENCE = 0,
+    /* One forward pass over [0,T-1] with full back-pointers + one backtrack.  Equal to the
+     * reference in exact arithmetic; float rounding histories of right-hand sub-tasks differ,
+     * so equality with the reference binary is empirical (it held on every fixture). */
+    FV_MODE_SINGLE_PASS = 1,
+};
+
+/* fv_set_option keys. */
+enum {
+    FV_OPT_KERNEL = 1,      /* FV_KERNEL_* : which trellis-step kernel streams the transition table */
+    FV_OPT_MAX_BATCH = 2,   /* 1..8: most independent tasks advanced by one step launch */
+    FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
+};
+enum {
+    FV_KERNEL_AUTO = 0,        /* F32_REFINE when every model entry is in [0,1], else F64_STREAM */
+    FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim */
+    FV_KERNEL_F32_REFINE = 2,  /* streams (float)log A (4 B/cell), brackets the winner within 2 ulp,
+                                  then re-evaluates the few candidates in float64: same bits out */
+};
+
+typedef struct {
+    double set_model_ms;      /* host log() tables + H2D of the last fv_set_model */
+    double decode_ms;         /* host wall time of the last decode call (enqueue .. final sync) */
+    double gpu_ms;            /* HIP-event time from first to last kernel of the last decode */
+    double top_pass_ms;       /* HIP-event time of generation 0 (the whole-sequence pass) */
+    double step_kernel_ms;    /* sum of per-launch event times of the step kernel (FV_OPT_PROFILE=1) */
+    long long step_launches;  /* trellis-step kernel launches in the last decode */
+    long long task_steps;     /* sum over launches of tasks advanced (= passes' total step count) */
+    long long cells;          /* add-compare cells: task_steps * K * K (full) or * K * beam */
+    long long alg_bytes;      /* 4 bytes per cell */
+    long long table_bytes_per_step; /* bytes of transition table one step launch streams */
+    long long device_bytes;   /* device working set (tables + workspace) */
+    long long refine_near;    /* F32_REFINE: candidates within 2 ulp of a column's best */
+    long long refine_rescan;  /* F32_REFINE: lanes that had to rescan their rows */
+    int passes;               /* forward passes run (reference mode: one per right-hand task) */
+    int generations;          /* dependent batches of passes */
+    int kernel;               /* FV_KERNEL_* actually used */
+    int ranks;                /* ranks sharing the decode (1 without fv_comm_init) */
+} fv_stats;
+
+/* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role
+ * (FLASH:97-107) and the ThreadPool globals (:36-46). */
+int fv_create(fv_ctx **out, int device);
+void fv_destroy(fv_ctx *ctx);
+
+/* Model upload.  A is K*K row-major A[from][to], B is K*M row-major B[state][symbol],
+ * Pi is K — the VIT fields of FLASH:26-28 as InitElement filled them (:82-93).  Takes
+ * log() of every entry in double with the host libm (the calls the reference makes per
+ * cell, :142,150,167,170) and ships the tables; the caller keeps ownership of A/B/Pi. */
+int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const float *Pi, int K, int M);
+
+int fv_set_option(fv_ctx *ctx, int key, long long value);
+
+/* calc() of FLASH_Viterbi_multithread.c:338-368 with MAX_THREADS = n_split:
+ * ob[T] = vit->Obroute, path_out[T] = vit->Ans, *score_out = T1[cur][Ans[T-1]] of the
+ * whole-sequence pass (the reference never prints it). */
+int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, int mode,
+                   int *path_out, float *score_out);
+
+/* calc() of FLASH_BS_Viterbi_multithread.c:548-577 with MAX_THREADS = n_split and
+ * BeamSearchWidth = beam_width (2 <= beam_width <= K). */
+int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode,
+                   int *path_out, float *score_out);
+
+int fv_last_stats(const fv_ctx *ctx, fv_stats *out);
+const char *fv_strerror(int rc);
+const char *fv_last_error_detail(const fv_ctx *ctx);
+
+/* vit->memory_bytes as the reference computes it (FLASH:355,364-367; FLASH_BS:564,573-576)
+ * — a sizeof formula, not a measurement; beam_width = 0 selects the full variant. */
+long long fv_reference_memory_bytes(int K, int T, int n_split, int beam_width);
+
+/* Multi-GPU: one process per GPU.  Rank 0 calls fv_comm_unique_id and hands the 128 bytes
+ * to every rank by any means (bench.py uses torch.distributed); every rank then calls
+ * fv_comm_init.  After that each decode call is collective: the whole-sequence pass runs
+ * on every rank, the n_split top-level segments (FLASH:349-353) are dealt round-robin to
+ * ranks, and one RCCL all-gather over xGMI merges the per-rank path slices.  Replaces the
+ * shared-memory work queue of worker() (FLASH:264-308). */
+#define FV_UNIQUE_ID_BYTES 128
+int fv_comm_unique_id(void *id_out);
+int fv_comm_init(fv_ctx *ctx, int rank, int nranks, const void *id);
+
+/* Host-side schedule, exposed so it can be tested without a GPU.  Fills at most `cap`
+ * entries of (L, R, generation, owner_rank) per forward pass, in launch order, and returns
+ * the number of passes (or <0).  Pass 0 is always the whole-sequence pass. */
+typedef struct { int L, R, generation, owner; } fv_pass_info;
+int fv_plan_passes(int T, int n_split, int mode, int nranks, fv_pass_info *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""GPU parity of the full-state FLASH path, through the C-ABI (libflashvit.so).
+
+Bar: decoded path bit-exact (int32), final score float32-equal, against (1) golden
+vectors from the reference-built binaries and (2) the oracle on fresh seeded inputs."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_model, golden_runs
+from flash_viterbi_amd import decoder
+
+pytestmark = pytest.mark.gpu
+
+PAIRS, IDS = golden_runs(include_big=True, algo="flash")
+KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE]
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    cache = {}
+
+    def get(g):
+        if g["name"] not in cache:
+            A, B, Pi, ob = golden_model(g)
+            fv = decoder.FlashViterbi(0)
+            fv.set_model(A, B, Pi)
+            cache[g["name"]] = (fv, ob)
+        return cache[g["name"]]
+    yield get
+    for fv, _ in cache.values():
+        fv.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine"])
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_reference_mode_matches_golden(ctxs, g, r, kernel):
+    fv, ob = ctxs(g)
+    fv.set_option(decoder.OPT_KERNEL, kernel)
+    path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)
+    assert rc == 0
+    assert path.tolist() == r["path"]
+    assert score == np.float32(r["score"])
+    st = fv.stats()
+    assert st["kernel"] == kernel
+    assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"]) == r["memory"]
+
+
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_single_pass_mode_matches_golden_empirically(ctxs, g, r):
+    """Not guaranteed by construction (different rounding history for right-hand tasks) but it
+    holds on every fixture; a failure here is information, not necessarily a bug."""
+    fv, ob = ctxs(g)
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_SINGLE_PASS)
+    assert rc == 0 and score == np.float32(r["score"])
+    if g["spec"]["kind"] == "data_script":
+        assert path.tolist() == r["path"]
+
+
+@pytest.mark.parametrize("K,M,T,N,seed,prob", [(300, 11, 70, 4, 101, 0.15), (1000, 50, 40, 3, 102, 0.15),
+                                               (65, 5, 129, 8, 103, 0.15), (2049, 20, 24, 1, 104, 0.15),
+                                               (16, 3, 200, 16, 105, 0.8)])
+def test_reference_mode_matches_oracle_fresh_inputs(K, M, T, N, seed, prob):
+    import modelgen
+    spec = dict(kind="data_script", K=K, M=M, T=T, prob=prob, seed=seed)
+    A, B, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, B, Pi)
+    opath, oscore, ocells, orc = om.full_decode(ob, N)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    for kernel in KERNELS:
+        for batch in (1, 8):
+            fv.set_option(decoder.OPT_KERNEL, kernel)
+            fv.set_option(decoder.OPT_MAX_BATCH, batch)
+            path, score, rc = fv.decode_full(ob, N)
+            assert rc == 0 and path.tolist() == opath.tolist() and score == oscore
+    fv.close()
+
+
+def test_model_above_one_falls_back_to_f64_stream():
+    """Unnormalised weights (> 1) void the F32_REFINE bracket; AUTO must pick F64_STREAM and still match."""
+    rs = np.random.RandomState(5)
+    K, M, T = 96, 6, 50
+    A = (rs.uniform(0, 3, (K, K)) * (rs.uniform(0, 1, (K, K)) < 0.3)).astype(np.float32)
+    A[np.arange(K), rs.randint(0, K, K)] = 1.5
+    B = rs.uniform(0.1, 2, (K, M)).astype(np.float32)
+    Pi = rs.uniform(0.1, 1, K).astype(np.float32)
+    ob = rs.randint(0, M, T).astype(np.int32)
+    om = oracle.OracleModel(A, B, Pi)
+    opath, oscore, _, _ = om.full_decode(ob, 4)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    path, score, rc = fv.decode_full(ob, 4)
+    assert fv.stats()["kernel"] == decoder.KERNEL_F64_STREAM
+    assert path.tolist() == opath.tolist() and score == oscore
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F32_REFINE)
+    with pytest.raises(decoder.FlashVitError):
+        fv.decode_full(ob, 4)
+    fv.close()
+
+
+def test_argument_errors():
+    fv = decoder.FlashViterbi(0)
+    with pytest.raises(decoder.FlashVitError):
+        fv.decode_full(np.zeros(4, np.int32), 1)            # no model yet
+    A = np.full((4, 4), 0.25, np.float32)
+    fv.set_model(A, A[:, :2] * 2, A[0])
+    with pytest.raises(decoder.FlashVitError):
+        fv.decode_full(np.array([0, 5, 1], np.int32), 1)    # symbol out of range
+    with pytest.raises(decoder.FlashVitError):
+        fv.decode_full(np.zeros(8, np.int32), 4)            # T == 2N
+    bad = A.copy(); bad[1, 1] = -0.1
+    with pytest.raises(decoder.FlashVitError):
+        fv.set_model(bad, A[:, :2] * 2, A[0])
+    fv.close()

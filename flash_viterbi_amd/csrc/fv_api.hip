@@ -51,8 +51,7 @@ struct fv_ctx {
     std::string detail;
 
     // model
-    int K = 0, M = 0, nrows = 0, rows_alloc = 0;
-    long long pitch = 0;
+    int K = 0, M = 0, nrows = 0;
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
     DevBuf<double> LA64, LB64T, LPi64;
@@ -69,7 +68,9 @@ struct fv_ctx {
     int opt_kernel = FV_KERNEL_AUTO;
     int opt_max_batch = fvk::MAX_BATCH;
     int opt_profile = 0;
+    int opt_debug = 0;       // FV_OPT_DEBUG bits: 1 skip refine (timing only), 2 no reverse sweep, 4 alternate unroll
     std::vector<hipEvent_t> prof_events;
+    std::vector<int> h_ob;
 
     // comm
     ncclComm_t comm = nullptr;
@@ -124,42 +125,51 @@ int pick_kernel(const fv_ctx *ctx)
     return ctx->logs_nonpositive ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
 }
 
+constexpr int U_F32 = 4, U_F64 = 2, U_ALT = 2;
+
 template <typename TA, int NB>
-int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32)
+int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int reverse)
 {
     fvk::StepArgs<NB> a;
     a.LA = f32 ? (const void *)ctx->LA32.p : (const void *)ctx->LA64.p;
     a.LA64 = ctx->LA64.p;
-    a.LB32T = ctx->LB32T.p;
-    a.ob = ctx->d_ob.p;
     a.counters = ctx->d_counters.p;
-    a.pitch = ctx->pitch;
     a.K = ctx->K;
+    a.reverse = (ctx->opt_debug & 2) ? 0 : reverse;
+    a.debug = ctx->opt_debug;
     a.nrows = ctx->nrows;
     a.ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     a.nb = nb;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
-    hipLaunchKernelGGL((fvk::trellis_step<TA, NB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    constexpr int U = sizeof(TA) == 4 ? U_F32 : U_F64;
+    if (sizeof(TA) == 4 && NB == 1 && (ctx->opt_debug & 4))
+        hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U_ALT>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
     FV_HIP(hipGetLastError());
     return 0;
 }
 
 template <typename TA>
-int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32)
+int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int reverse)
 {
-    if (nb <= 1) return launch_step_nb<TA, 1>(ctx, slots, nb, f32);
-    if (nb <= 2) return launch_step_nb<TA, 2>(ctx, slots, nb, f32);
-    if (nb <= 4) return launch_step_nb<TA, 4>(ctx, slots, nb, f32);
-    return launch_step_nb<TA, 8>(ctx, slots, nb, f32);
+    if (nb <= 1) return launch_step_nb<TA, 1>(ctx, slots, nb, f32, reverse);
+    if (nb <= 2) return launch_step_nb<TA, 2>(ctx, slots, nb, f32, reverse);
+    if (nb <= 4) return launch_step_nb<TA, 4>(ctx, slots, nb, f32, reverse);
+    return launch_step_nb<TA, 8>(ctx, slots, nb, f32, reverse);
 }
 
 template <typename TA, int NB>
 int allow_big_lds(fv_ctx *ctx)
 {
-    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB>),
+    constexpr int U = sizeof(TA) == 4 ? U_F32 : U_F64;
+    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (sizeof(TA) == 4 && NB == 1)
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_ALT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
 
@@ -219,7 +229,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
             ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * K };
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
-                           ctx->LA64.p, ctx->pitch, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
+                           ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
                            ctx->d_rows.p, K);
         FV_HIP(hipGetLastError());
     }
@@ -236,7 +246,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
                 float *r0 = ctx->d_rows.p + (size_t)(base + q) * 2 * K;
                 slots[q].t1_in = r0 + (size_t)((s - 1) & 1) * K;
                 slots[q].t1_out = r0 + (size_t)(s & 1) * K;
-                slots[q].j = p.L + s;
+                slots[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
             }
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -246,7 +256,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
                 nprof += 2;
                 FV_HIP(hipEventRecord(e0, ctx->stream));
             }
-            int rc = f32 ? launch_step<float>(ctx, slots, nb, true) : launch_step<double>(ctx, slots, nb, false);
+            int rc = f32 ? launch_step<float>(ctx, slots, nb, true, s & 1) : launch_step<double>(ctx, slots, nb, false, s & 1);
             if (rc) return rc;
             if (ctx->opt_profile) FV_HIP(hipEventRecord(e1, ctx->stream));
             ctx->stats.step_launches += 1;
@@ -381,12 +391,11 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     if (!ctx || !A || !B || !Pi || K < 1 || M < 1) return FV_ERR_ARG;
     auto t0 = clk::now();
     FV_HIP(hipSetDevice(ctx->device));
-    const int nrows = round_up(K, fvk::ROWS_PER_IT);
-    const int rows_alloc = nrows + fvk::ROWS_PER_IT;       // at least one full block of -inf rows
-    const long long pitch = nrows;
+    const int nrows = round_up(K, fvk::RB_ROWS);
+    const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
     if (fvk::step_lds_bytes<1>(nrows) > 160 * 1024) return FV_ERR_UNSUPPORTED;   // one score row must fit LDS
 
-    const size_t tab = (size_t)rows_alloc * pitch;
+    const size_t tab = (size_t)ntiles * nrows * fvk::TILE_W;
     std::vector<double> h64;
     std::vector<float> h32;
     try { h64.assign(tab, -HUGE_VAL); h32.assign(tab, -HUGE_VALF); } catch (...) { return FV_ERR_NOMEM; }
@@ -395,14 +404,13 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     parallel_rows(K, [&](int a, int b) {
         for (int k = a; k < b; ++k) {
             const float *src = A + (size_t)k * K;
-            double *d = h64.data() + (size_t)k * pitch;
-            float *f = h32.data() + (size_t)k * pitch;
             for (int i = 0; i < K; ++i) {
                 const float x = src[i];
                 if (!(x >= 0.0f) || std::isinf(x)) bad[k] = 1;
                 if (x > 1.0f) big[k] = 1;
                 const double l = std::log((double)x);
-                d[i] = l; f[i] = (float)l;
+                const size_t e = fvk::tab_index(k, i, nrows);
+                h64[e] = l; h32[e] = (float)l;
             }
         }
     });
@@ -435,7 +443,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LB64T.p, b64.data(), b64.size() * sizeof(double), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->rows_alloc = rows_alloc; ctx->pitch = pitch;
+    ctx->K = K; ctx->M = M; ctx->nrows = nrows;
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = ms_since(t0);
@@ -455,6 +463,8 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
         ctx->opt_max_batch = (int)value; return FV_OK;
     case FV_OPT_PROFILE:
         ctx->opt_profile = value ? 1 : 0; return FV_OK;
+    case FV_OPT_DEBUG:
+        ctx->opt_debug = (int)value; return FV_OK;
     default: return FV_ERR_ARG;
     }
 }
@@ -488,9 +498,10 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     ctx->stats.set_model_ms = keep_model_ms;
     ctx->stats.kernel = f32 ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
     ctx->stats.generations = plan.generations();
-    ctx->stats.table_bytes_per_step = (long long)ctx->nrows * ctx->pitch * (f32 ? 4 : 8);
+    ctx->stats.table_bytes_per_step = (long long)((ctx->K + fvk::TILE_W - 1) / fvk::TILE_W) * ctx->nrows * fvk::TILE_W * (f32 ? 4 : 8);
 
-    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ob, (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_ob.assign(ob, ob + T);
+    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));

@@ -53,6 +53,7 @@ enum {
     FV_OPT_KERNEL = 1,      /* FV_KERNEL_* : which trellis-step kernel streams the transition table */
     FV_OPT_MAX_BATCH = 2,   /* 1..8: most independent tasks advanced by one step launch */
     FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
+    FV_OPT_DEBUG = 100,     /* kernel-tuning switches for timing experiments only (bit0 voids results) */
 };
 enum {
     FV_KERNEL_AUTO = 0,        /* F32_REFINE when every model entry is in [0,1], else F64_STREAM */

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — FLASH Viterbi decode throughput on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete decode of the BASELINE workload (configs[1]): K=3965 states,
+T=256 observations, M=50 symbols, generate_data model (-s 12 -p 0.112), n_split=8, in
+FV_MODE_REFERENCE (the reference's divide-and-conquer task tree replayed pass for pass,
+bit-exact by construction), model tables already resident in HBM (fv_set_model is outside the
+timed region; the 1 KB observation upload and 1 KB path download are inside it).
+
+metric = trellis cells/s with cells = K*K*T per decode (BASELINE.json's K·K·T ops).
+
+N > 1: the n_split top-level segments are dealt round-robin to ranks (one process per GPU),
+every rank runs the whole-sequence pass, one RCCL all-gather merges the path slices
+(include/flashvit.h, fv_comm_init).  Same total work for every N => "scaling": "strong".
+The whole-sequence pass is serial in T, so the curve is Amdahl-bound (Multi-GPU).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from flash_viterbi_amd import decoder, hostio  # noqa: E402
+from flash_viterbi_amd.generate_data import data_script  # noqa: E402
+
+K, M, T, PROB, SEED, N_SPLIT = 3965, 50, 256, 0.112, 12, 8
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+CPU_SAMPLE_T = 64            # bounded CPU-baseline sample: first 64 observations of the same workload
+CPU_THREADS = 8
+
+
+def build_workload():
+    A64, B64, Pi64 = data_script.make_model64(K, M, SEED, PROB)
+    A, B, Pi = hostio.quantize_text16(A64), hostio.quantize_text16(B64), hostio.quantize_text16(Pi64)
+    ob = np.asarray(data_script.make_observations(T, M, SEED), dtype=np.int32)
+    return (A64, B64, Pi64), (A, B, Pi), ob
+
+
+def cpu_baseline(model64, ob, hip_path_sample):
+    """Reference pthread program (compiled from the reference's own sources into oracle/_ref by
+    oracle/build_ref.py) on a bounded sample; falls back to the oracle port if the binary is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    A64, B64, Pi64 = model64
+    sample = f"K={K} T={CPU_SAMPLE_T} (first {CPU_SAMPLE_T} observations of the bench workload), MAX_THREADS={CPU_THREADS}"
+    try:
+        exe = build_ref.build("flash", K, CPU_SAMPLE_T, PROB, CPU_THREADS)
+    except FileNotFoundError:
+        exe = None
+    if exe:
+        tmp = tempfile.mkdtemp(prefix="fvbench_")
+        try:
+            data_script.write_files(tmp, K, CPU_SAMPLE_T, PROB, A64, B64, Pi64, ob[:CPU_SAMPLE_T], text=True)
+            out = build_ref.run(exe, tmp, timeout=1200)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return {"value": K * K * CPU_SAMPLE_T / out["time"], "unit": "cells/s", "cores": CPU_THREADS,
+                "kind": "reference", "seconds": out["time"],
+                "sample": sample + "; reference src/FLASH_Viterbi_multithread.c built with run.py:54 flags, its own `time:` line",
+                "path_equal_to_hip": bool(out["path"] == hip_path_sample)}
+    import oracle
+    oracle.set_threads(CPU_THREADS)
+    om = oracle.OracleModel(hostio.quantize_text16(A64), hostio.quantize_text16(B64), hostio.quantize_text16(Pi64))
+    t0 = time.time()
+    path, _, _, _ = om.full_decode(ob[:CPU_SAMPLE_T], CPU_THREADS)
+    dt = time.time() - t0
+    return {"value": K * K * CPU_SAMPLE_T / dt, "unit": "cells/s", "cores": CPU_THREADS, "kind": "port",
+            "seconds": dt, "sample": sample + "; oracle/flashvit_oracle.c (OpenMP), log tables precomputed",
+            "path_equal_to_hip": bool(path.tolist() == hip_path_sample)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    model64, (A, B, Pi), ob = build_workload()
+    dist = None
+    if "RANK" in os.environ:      # launched by torch.distributed.run (also exercised with 1 rank)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    fv = decoder.FlashViterbi(local_rank)
+    fv.set_model(A, B, Pi)
+    if dist is not None:
+        # torch.distributed is the rendezvous only: the 128-byte RCCL id travels over it, the
+        # data-path collective (one all-gather per decode) is issued by libflashvit on its own stream
+        uid = [decoder.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        fv.comm_init(rank, world, uid[0])
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE)
+    barrier()
+    t0 = time.perf_counter()
+    top_ms = steps_ms = 0.0
+    for _ in range(args.steps):
+        path, score, rc = fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE)   # synchronous: returns after its stream drained
+        s_ = fv.stats()
+        top_ms += s_["top_pass_ms"]
+        steps_ms += s_["top_steps_ms"]      # HIP events (library's stream) around the T-1 step launches of the whole-sequence pass
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    st = fv.stats()
+
+    # roofline of the dominant kernel (trellis_step with 1 task per launch = the whole-sequence pass):
+    # average launch duration = HIP-event time around its T-1 back-to-back launches in the TIMED region
+    # divided by T-1, i.e. kernel time plus the dispatch gap to the next launch (rocprofv3's per-kernel
+    # average, profiles/, excludes part of that gap and reads ~8 % lower).
+    launch_us = 1e3 * (steps_ms / args.steps) / (T - 1)
+    alg_bytes_per_launch = 4.0 * K * K                      # 4 B per trellis cell, K*K cells per step
+    achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
+    ps_ = fv.decode_full(ob, N_SPLIT, decoder.MODE_SINGLE_PASS)
+    ps = fv.stats()
+    traffic = None
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.isfile(tr_file):
+        with open(tr_file) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+
+    if rank == 0:
+        line = {
+            "metric": "trellis_cells_per_sec", "value": K * K * T * args.steps / dt, "unit": "cells/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 scores (+f64 add per cell, rounded to f32 as the reference does)",
+            "data": "synthetic",
+            "config": {"workload": f"FLASH Viterbi full-state decode K={K} T={T} M={M} prob={PROB} seed={SEED} "
+                                   f"n_split={N_SPLIT} mode=reference (BASELINE configs[1])",
+                       "kernel": {1: "f64_stream", 2: "f32_refine"}[st["kernel"]],
+                       "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
+                       "parallelism": f"segments over {args.gpus} rank(s)"},
+            "decode_ms": 1e3 * dt / args.steps,
+            "forward_pass_ms": top_ms / args.steps,
+            "forward_pass_cells_per_sec": K * K * (T - 1) / (1e-3 * top_ms / args.steps),
+            "single_pass_mode_ms": ps["gpu_ms"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "fvk::trellis_step<float,1,4,true>", "launch_us": launch_us,
+                         "alg_bytes_per_launch": alg_bytes_per_launch, "launches_per_decode": T - 1,
+                         "table_bytes_streamed_per_launch": ps["table_bytes_per_step"]},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            hip_sample, _, _ = fv.decode_full(ob[:CPU_SAMPLE_T], CPU_THREADS, decoder.MODE_REFERENCE)
+            line["cpu_baseline"] = cpu_baseline(model64, ob, hip_sample.tolist())
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    fv.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,7 +47,7 @@ struct DevBuf {
 struct fv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     std::string detail;
 
     // model
@@ -125,7 +125,20 @@ int pick_kernel(const fv_ctx *ctx)
     return ctx->logs_nonpositive ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
 }
 
-constexpr int U_F32 = 4, U_F64 = 2, U_ALT = 2;
+// Kernel variants.  Default: chunks of U 16-byte loads per lane, double-buffered in registers.
+// "Upfront" (one register buffer holding the wave's whole share of the tile, requested before the
+// score row is staged) measured SLOWER at K=3965 (16.3 vs 12.9 us/step): with every workgroup's
+// whole tile in flight the L2 lines kept from the previous (opposite-direction) sweep are evicted
+// before they are re-read.  Kept behind FV_OPT_DEBUG bit 2 for experiments.
+constexpr int U_UP32 = 16, U_DB32 = 4, U_DB64 = 2;
+
+template <typename TA, int NB, int U, bool DB>
+int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
+{
+    hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U, DB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
 
 template <typename TA, int NB>
 int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int reverse)
@@ -143,13 +156,15 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, in
     a.nb = nb;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
-    constexpr int U = sizeof(TA) == 4 ? U_F32 : U_F64;
-    if (sizeof(TA) == 4 && NB == 1 && (ctx->opt_debug & 4))
-        hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U_ALT>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
-    FV_HIP(hipGetLastError());
-    return 0;
+    const int nj_max = (ctx->nrows / fvk::RB_ROWS + fvk::NWAVES - 1) / fvk::NWAVES;
+    if constexpr (sizeof(TA) == 4) {
+        if constexpr (NB <= 2) {
+            if (nj_max <= U_UP32 && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP32, false>(ctx, a, lds);
+        }
+        return launch_variant<TA, NB, U_DB32, true>(ctx, a, lds);
+    } else {
+        return launch_variant<TA, NB, U_DB64, true>(ctx, a, lds);
+    }
 }
 
 template <typename TA>
@@ -164,12 +179,17 @@ int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int r
 template <typename TA, int NB>
 int allow_big_lds(fv_ctx *ctx)
 {
-    constexpr int U = sizeof(TA) == 4 ? U_F32 : U_F64;
-    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    if (sizeof(TA) == 4 && NB == 1)
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_ALT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int big = 160 * 1024;
+    if constexpr (sizeof(TA) == 4) {
+        if constexpr (NB <= 2)
+            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_UP32, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_DB32, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    } else {
+        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_DB64, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    }
     return 0;
 }
 
@@ -194,7 +214,7 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
     FV_HIP(ctx->d_rows.ensure(rows_needed * 2 * ctx->K));
     FV_HIP(ctx->d_score.ensure(4));
     FV_HIP(ctx->d_counters.ensure(4));
-    if (ctx->nranks > 1) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
+    if (ctx->comm) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
     return 0;
 }
 
@@ -236,6 +256,8 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
     const int maxlen = passes[0].R - passes[0].L;
     const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows)));
     int active = np;
+    const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
+    if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     for (int s = 1; s <= maxlen; ++s) {
         while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
         for (int base = 0; base < active; base += cap) {
@@ -263,6 +285,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
             ctx->stats.task_steps += nb;
         }
     }
+    if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream));
     // end states + chains
     for (int q = 0; q < np; ++q) {
         if (!passes[q].whole) continue;
@@ -301,7 +324,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
                   size_t nprof, bool beam)
 {
     std::vector<int> host;
-    if (ctx->nranks > 1 && !plan.seg_L.empty()) {
+    if (ctx->comm && !plan.seg_L.empty()) {
         ncclResult_t nr = ncclAllGather(ctx->d_ans.p, ctx->d_gather.p, (size_t)T, ncclInt32, ctx->comm, ctx->stream);
         if (nr != ncclSuccess) { ctx->detail = std::string("ncclAllGather: ") + ncclGetErrorString(nr); return FV_ERR_COMM; }
         host.resize((size_t)T * ctx->nranks);
@@ -324,6 +347,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     float ms = 0.f;
     FV_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop)); st.gpu_ms = ms;
     FV_HIP(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_top)); st.top_pass_ms = ms;
+    FV_HIP(hipEventElapsedTime(&ms, ctx->ev_s0, ctx->ev_s1)); st.top_steps_ms = ms;
     st.step_kernel_ms = 0;
     for (size_t i = 0; i + 1 < nprof; i += 2) {
         FV_HIP(hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
@@ -356,7 +380,8 @@ extern "C" int fv_create(fv_ctx **out, int device)
     if (hipSetDevice(device) != hipSuccess) return fail(FV_ERR_DEVICE);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(FV_ERR_DEVICE);
     if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
-        hipEventCreate(&ctx->ev_top) != hipSuccess)
+        hipEventCreate(&ctx->ev_top) != hipSuccess || hipEventCreate(&ctx->ev_s0) != hipSuccess ||
+        hipEventCreate(&ctx->ev_s1) != hipSuccess)
         return fail(FV_ERR_DEVICE);
     int rc = 0;
     if ((rc = allow_big_lds<float, 1>(ctx)) || (rc = allow_big_lds<float, 2>(ctx)) || (rc = allow_big_lds<float, 4>(ctx)) ||
@@ -382,6 +407,8 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_top) (void)hipEventDestroy(ctx->ev_top);
+    if (ctx->ev_s0) (void)hipEventDestroy(ctx->ev_s0);
+    if (ctx->ev_s1) (void)hipEventDestroy(ctx->ev_s1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -21,7 +21,8 @@ UNIQUE_ID_BYTES = 128
 
 class Stats(ctypes.Structure):
     _fields_ = [("set_model_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("gpu_ms", ctypes.c_double),
-                ("top_pass_ms", ctypes.c_double), ("step_kernel_ms", ctypes.c_double),
+                ("top_pass_ms", ctypes.c_double), ("top_steps_ms", ctypes.c_double),
+                ("step_kernel_ms", ctypes.c_double),
                 ("step_launches", ctypes.c_longlong), ("task_steps", ctypes.c_longlong),
                 ("cells", ctypes.c_longlong), ("alg_bytes", ctypes.c_longlong),
                 ("table_bytes_per_step", ctypes.c_longlong), ("device_bytes", ctypes.c_longlong),

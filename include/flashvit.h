@@ -66,7 +66,8 @@ typedef struct {
     double set_model_ms;      /* host log() tables + H2D of the last fv_set_model */
     double decode_ms;         /* host wall time of the last decode call (enqueue .. final sync) */
     double gpu_ms;            /* HIP-event time from first to last kernel of the last decode */
-    double top_pass_ms;       /* HIP-event time of generation 0 (the whole-sequence pass) */
+    double top_pass_ms;       /* HIP-event time of generation 0 (the whole-sequence pass incl. init/argmax/backtrack) */
+    double top_steps_ms;      /* HIP-event time around generation 0's T-1 back-to-back step launches only */
     double step_kernel_ms;    /* sum of per-launch event times of the step kernel (FV_OPT_PROFILE=1) */
     long long step_launches;  /* trellis-step kernel launches in the last decode */
     long long task_steps;     /* sum over launches of tasks advanced (= passes' total step count) */

@@ -27,6 +27,10 @@ enum {
 
 typedef struct fvo_model fvo_model;
 
+/* OpenMP threads the per-step loops over destination states use (results do not depend on it);
+ * returns the number in effect. */
+int fvo_set_threads(int n);
+
 /* Takes log() of every model entry in double with this host's libm, exactly the
  * calls the reference makes per trellis cell (FLASH_Viterbi_multithread.c:142,150,167,170). */
 fvo_model *fvo_model_create(const float *A, const float *B, const float *Pi, int K, int M);

@@ -33,6 +33,12 @@ def lib():
     global _lib
     if _lib is None:
         L = ctypes.CDLL(build())
+        # never more OpenMP threads than the CPUs this process may run on (a GPU box's cgroup share)
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        L.fvo_set_threads(min(ncpu, 16))
         vp, ci = ctypes.c_void_p, ctypes.c_int
         L.fvo_model_create.restype = vp
         L.fvo_model_create.argtypes = [vp, vp, vp, ci, ci]
@@ -40,12 +46,17 @@ def lib():
         L.fvo_full_decode.argtypes = [vp, vp, ci, ci, vp, vp, vp]
         L.fvo_beam_decode.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp]
         L.fvo_full_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+        L.fvo_set_threads.argtypes = [ci]
         L.fvo_full_memory_bytes.restype = ctypes.c_longlong
         L.fvo_full_memory_bytes.argtypes = [ci, ci, ci]
         L.fvo_beam_memory_bytes.restype = ctypes.c_longlong
         L.fvo_beam_memory_bytes.argtypes = [ci, ci, ci, ci]
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    return int(lib().fvo_set_threads(n))
 
 
 class OracleError(RuntimeError):

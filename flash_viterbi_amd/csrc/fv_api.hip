@@ -543,11 +543,130 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     return finish_decode(ctx, plan, T, path_out, score_out, t0, nprof, false);
 }
 
+namespace {
+
+// One generation of beam passes in lock-step (same shape as run_generation_full).
+int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam)
+{
+    const int K = ctx->K, np = (int)passes.size();
+    if (np == 0) return 0;
+    std::stable_sort(passes.begin(), passes.end(),
+                     [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
+    auto scores_of = [&](int q) { return ctx->d_scores.p + (size_t)q * K; };
+    auto hval_of = [&](int q, int par) { return ctx->d_hval.p + ((size_t)q * 2 + par) * beam; };
+    auto hstate_of = [&](int q, int par) { return ctx->d_hstate.p + ((size_t)q * 2 + par) * beam; };
+    auto build_heaps = [&](int count, int par) -> int {
+        for (int base = 0; base < count; base += fvb::BEAM_CHUNK) {
+            fvb::HeapArgs h;
+            h.K = K; h.beam = beam; h.n = std::min(fvb::BEAM_CHUNK, count - base);
+            for (int q = 0; q < h.n; ++q) h.p[q] = fvb::HeapJob{ scores_of(base + q), hval_of(base + q, par), hstate_of(base + q, par) };
+            hipLaunchKernelGGL(fvb::heap_build, dim3(h.n), dim3(64), fvb::heap_lds(beam), ctx->stream, h);
+            FV_HIP(hipGetLastError());
+        }
+        return 0;
+    };
+    // init scores (the same rows the full variant starts from, FLASH_BS:407-427), then the first heaps
+    for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
+        fvk::PassChunk ch;
+        ch.n = std::min(fvk::PASS_CHUNK, np - base);
+        for (int q = 0; q < ch.n; ++q) {
+            const fv::Pass &p = passes[base + q];
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * K };
+        }
+        hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
+                           ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
+                           ctx->d_scores.p, K);
+        FV_HIP(hipGetLastError());
+    }
+    int rc = build_heaps(np, 0);
+    if (rc) return rc;
+    const int maxlen = passes[0].R - passes[0].L;
+    const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
+    int active = np;
+    for (int s = 1; s <= maxlen; ++s) {
+        while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
+        for (int base = 0; base < active; base += fvb::BEAM_CHUNK) {
+            fvb::BeamStepArgs a;
+            a.LA64 = ctx->LA64.p; a.K = K; a.nrows = ctx->nrows; a.beam = beam; a.ntiles = ntiles;
+            a.n = std::min(fvb::BEAM_CHUNK, active - base);
+            for (int q = 0; q < a.n; ++q) {
+                const fv::Pass &p = passes[base + q];
+                a.p[q].hval = hval_of(base + q, (s - 1) & 1);
+                a.p[q].hstate = hstate_of(base + q, (s - 1) & 1);
+                a.p[q].scores = scores_of(base + q);
+                a.p[q].bp_row = ctx->d_bp.p + (size_t)(p.L + s) * K;
+                a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
+            }
+            hipLaunchKernelGGL(fvb::beam_step, dim3(ntiles, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
+                               ctx->stream, a);
+            FV_HIP(hipGetLastError());
+            ctx->stats.step_launches += 1;
+            ctx->stats.task_steps += a.n;
+        }
+        if ((rc = build_heaps(active, s & 1))) return rc;
+    }
+    for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
+        fvb::BeamEndArgs e;
+        e.K = K; e.beam = beam; e.n = std::min(fvb::BEAM_CHUNK, np - base);
+        for (int q = 0; q < e.n; ++q) {
+            const fv::Pass &p = passes[base + q];
+            const int par = (p.R - p.L) & 1;
+            e.p[q] = fvb::BeamEnd{ p.L, p.R, p.whole ? 1 : 0, hval_of(base + q, par), hstate_of(base + q, par) };
+        }
+        hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_bp.p,
+                           ctx->d_ans.p, ctx->d_score.p);
+        FV_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode,
                               int *path_out, float *score_out)
 {
-    (void)ctx; (void)ob; (void)T; (void)n_split; (void)beam_width; (void)mode; (void)path_out; (void)score_out;
-    return FV_ERR_UNSUPPORTED;
+    if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
+    if (ctx->K == 0) return FV_ERR_STATE;
+    // beam > K reads uninitialised heap slots in the reference
+    if (beam_width < 2 || beam_width > ctx->K) return FV_ERR_ARG;
+    if (fvb::beam_step_lds(beam_width) > 160 * 1024 || fvb::heap_lds(beam_width) > 160 * 1024) return FV_ERR_UNSUPPORTED;
+    for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
+    auto t0 = clk::now();
+    FV_HIP(hipSetDevice(ctx->device));
+    fv::Plan plan;
+    int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
+    if (rc) return rc;
+    std::vector<std::vector<fv::Pass>> gens(plan.generations());
+    size_t most = 1;
+    for (const fv::Pass &p : plan.passes)
+        if (p.owner < 0 || p.owner % ctx->nranks == ctx->rank) gens[p.generation].push_back(p);
+    for (auto &g : gens) most = std::max(most, g.size());
+    if ((rc = ensure_workspace(ctx, T, 1))) return rc;
+    FV_HIP(ctx->d_scores.ensure(most * ctx->K));
+    FV_HIP(ctx->d_hval.ensure(most * 2 * beam_width));
+    FV_HIP(ctx->d_hstate.ensure(most * 2 * beam_width));
+
+    const double keep_model_ms = ctx->stats.set_model_ms;
+    ctx->stats = fv_stats{};
+    ctx->stats.set_model_ms = keep_model_ms;
+    ctx->stats.kernel = FV_KERNEL_F64_STREAM;
+    ctx->stats.generations = plan.generations();
+    ctx->stats.table_bytes_per_step = (long long)beam_width * ctx->K * 8;
+
+    ctx->h_ob.assign(ob, ob + T);
+    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
+    for (size_t g = 0; g < gens.size(); ++g) {
+        ctx->stats.passes += (int)gens[g].size();
+        if ((rc = run_generation_beam(ctx, gens[g], beam_width))) return rc;
+        if (g == 0) { FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream)); FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream)); }
+    }
+    ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * beam_width;
+    ctx->stats.alg_bytes = 4 * ctx->stats.cells;
+    return finish_decode(ctx, plan, T, path_out, score_out, t0, 0, true);
 }
 
 extern "C" int fv_last_stats(const fv_ctx *ctx, fv_stats *out)

@@ -1,0 +1,84 @@
+"""GPU parity of the FLASH-BS (dynamic beam) path through the C-ABI.
+
+Bar: decoded path bit-exact — including the -1 entries the reference prints after a beam miss —
+and final score float32-equal, against golden vectors from the reference-built binaries and
+against the oracle on fresh seeded inputs."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_model, golden_runs
+from flash_viterbi_amd import decoder
+
+pytestmark = pytest.mark.gpu
+
+PAIRS, IDS = golden_runs(include_big=True, algo="flashbs")
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    cache = {}
+
+    def get(g):
+        if g["name"] not in cache:
+            A, B, Pi, ob = golden_model(g)
+            fv = decoder.FlashViterbi(0)
+            fv.set_model(A, B, Pi)
+            cache[g["name"]] = (fv, ob)
+        return cache[g["name"]]
+    yield get
+    for fv, _ in cache.values():
+        fv.close()
+
+
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_beam_reference_mode_matches_golden(ctxs, g, r):
+    fv, ob = ctxs(g)
+    path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
+    assert path.tolist() == r["path"]
+    assert score == np.float32(r["score"])
+    assert rc == (decoder.WARN_BEAM_MISS if -1 in r["path"] else 0)
+    assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"], r["B"]) == r["memory"]
+
+
+@pytest.mark.parametrize("K,M,T,N,B,seed,prob", [(300, 11, 70, 4, 20, 201, 0.15), (1000, 50, 40, 3, 128, 202, 0.1),
+                                                 (65, 5, 129, 8, 65, 203, 0.3), (2049, 20, 24, 1, 500, 204, 0.05),
+                                                 (130, 4, 90, 16, 2, 205, 0.5), (700, 9, 33, 5, 699, 206, 0.2)])
+def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
+    import modelgen
+    spec = dict(kind="data_script", K=K, M=M, T=T, prob=prob, seed=seed)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, N, B)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    path, score, rc = fv.decode_beam(ob, N, B)
+    assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+    fv.close()
+
+
+def test_beam_equal_to_K_is_full_decode():
+    """B = K keeps every state: same path and score as the full-state decoder."""
+    import modelgen
+    spec = dict(kind="data_script", K=128, M=10, T=64, prob=0.3, seed=77)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    fpath, fscore, _ = fv.decode_full(ob, 4)
+    om = oracle.OracleModel(A, Bm, Pi)
+    bo, so, _, _ = om.beam_decode(ob, 4, 128)
+    bpath, bscore, _ = fv.decode_beam(ob, 4, 128)
+    assert bpath.tolist() == bo.tolist() and bscore == so
+    assert bscore == fscore
+    fv.close()
+
+
+def test_beam_argument_errors():
+    fv = decoder.FlashViterbi(0)
+    A = np.full((8, 8), 0.125, np.float32)
+    fv.set_model(A, A[:, :2] * 4, A[0])
+    ob = np.zeros(10, np.int32)
+    for bad in (1, 9):
+        with pytest.raises(decoder.FlashVitError):
+            fv.decode_beam(ob, 1, bad)
+    fv.close()

@@ -712,6 +712,17 @@ extern "C" long long fv_reference_memory_bytes(int K, int T, int n_split, int be
     return mem + pool + 8;     // + sizeof(ThreadPool) + sizeof(size_t) (the sizeof(expr) quirk, FLASH:367)
 }
 
+extern "C" int fv_merge_paths(int T, int n_split, int nranks, const int *gathered, int *path_out)
+{
+    if (!gathered || !path_out || nranks < 1) return FV_ERR_ARG;
+    fv::Plan plan;
+    int rc = fv::build_plan(T, n_split, FV_MODE_REFERENCE, nranks, plan);
+    if (rc) return rc;
+    std::vector<int> g(gathered, gathered + (size_t)T * nranks);
+    merge_gathered(plan, g, T, nranks, path_out);
+    return FV_OK;
+}
+
 extern "C" int fv_comm_unique_id(void *id_out)
 {
     if (!id_out) return FV_ERR_ARG;

@@ -40,7 +40,7 @@ class PassInfo(ctypes.Structure):
 
 EXPORTS = ["fv_create", "fv_destroy", "fv_set_model", "fv_set_option", "fv_decode_full", "fv_decode_beam",
            "fv_last_stats", "fv_strerror", "fv_last_error_detail", "fv_reference_memory_bytes",
-           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes"]
+           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths"]
 
 _lib = None
 
@@ -73,6 +73,7 @@ def load_library():
     L.fv_comm_unique_id.argtypes = [vp]
     L.fv_comm_init.argtypes = [vp, ci, ci, vp]
     L.fv_plan_passes.argtypes = [ci, ci, ci, ci, ctypes.POINTER(PassInfo), ci]
+    L.fv_merge_paths.argtypes = [ci, ci, ci, vp, vp]
     _lib = L
     return L
 
@@ -93,6 +94,16 @@ def plan_passes(T, n_split, mode=MODE_REFERENCE, nranks=1):
     buf = (PassInfo * n)()
     L.fv_plan_passes(T, n_split, mode, nranks, buf, n)
     return [(p.L, p.R, p.generation, p.owner) for p in buf]
+
+
+def merge_paths(T, n_split, nranks, gathered):
+    """The product's post-all-gather merge (host C++), callable without a GPU."""
+    g = np.ascontiguousarray(gathered, dtype=np.int32).reshape(nranks * T)
+    out = np.empty(T, dtype=np.int32)
+    rc = load_library().fv_merge_paths(T, n_split, nranks, _p(g), _p(out))
+    if rc < 0:
+        raise FlashVitError(rc)
+    return out
 
 
 def reference_memory_bytes(K, T, n_split, beam=0):

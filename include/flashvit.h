@@ -125,6 +125,11 @@ long long fv_reference_memory_bytes(int K, int T, int n_split, int beam_width);
 int fv_comm_unique_id(void *id_out);
 int fv_comm_init(fv_ctx *ctx, int rank, int nranks, const void *id);
 
+/* The merge applied after the all-gather, exposed for CPU tests: gathered = nranks arrays of T
+ * answers (rank-major); position j is taken from the rank owning the top-level segment that
+ * contains it, segment end points from rank 0. */
+int fv_merge_paths(int T, int n_split, int nranks, const int *gathered, int *path_out);
+
 /* Host-side schedule, exposed so it can be tested without a GPU.  Fills at most `cap`
  * entries of (L, R, generation, owner_rank) per forward pass, in launch order, and returns
  * the number of passes (or <0).  Pass 0 is always the whole-sequence pass. */

@@ -1,0 +1,132 @@
+"""CPU: the drop-in boundary — libraries load without a GPU and export every symbol their
+headers declare, the host I/O reproduces the generate_data text format byte for byte, the
+product never touches the oracle, and the host programs accept the reference's run.py patching."""
+import ctypes
+import io
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_model, load_goldens
+from flash_viterbi_amd import build as fvbuild
+from flash_viterbi_amd import decoder, hostio
+
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def declared_functions(header):
+    text = open(os.path.join(INCLUDE, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fvh?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = decoder.load_library()          # dlopen works without a GPU
+    names = declared_functions("flashvit.h")
+    assert "fv_decode_full" in names and "fv_decode_beam" in names and "fv_comm_init" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/flashvit.h but not exported"
+    assert sorted(decoder.EXPORTS) == [n for n in names]
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = hostio.lib()
+    for n in declared_functions("flashvit_host.h"):
+        assert hasattr(lib, n), n
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(decoder.FlashVitError):
+        decoder.FlashViterbi(0)
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "flash_viterbi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".h", ".hip", ".inc")):
+                text = open(os.path.join(dirpath, f)).read()
+                for line in text.splitlines():
+                    if re.search(r"^\s*(import|from)\s+oracle|libfvoracle|fvo_", line):
+                        pytest.fail(f"{f}: product code refers to the oracle: {line.strip()}")
+    # and the shared library does not link it
+    out = subprocess.run(["ldd", fvbuild.HIP_LIB], capture_output=True, text=True).stdout
+    assert "fvoracle" not in out
+
+
+def test_text_writer_matches_numpy_savetxt_bytes(tmp_path):
+    rs = np.random.RandomState(0)
+    a = rs.uniform(0, 1, (7, 5)) * (rs.uniform(0, 1, (7, 5)) < 0.5)
+    a[0, 0] = 1e-9
+    a[1, 1] = 1.0
+    p = str(tmp_path / "m.txt")
+    hostio.write_matrix_text16(p, a)
+    ref = io.BytesIO()
+    np.savetxt(ref, a, fmt="%.16f")                   # reference generate_data/data_script.py:98
+    assert open(p, "rb").read() == ref.getvalue()
+    v = rs.uniform(0, 1, 9)
+    hostio.write_vector_text16(p, v)
+    ref = io.BytesIO()
+    np.savetxt(ref, v, fmt="%.16f", newline=" ")      # data_script.py:100
+    assert open(p, "rb").read() == ref.getvalue()
+    ob = rs.randint(0, 50, 11)
+    hostio.write_ints_text(p, ob)
+    ref = io.BytesIO()
+    np.savetxt(ref, ob, fmt="%d", newline=" ")        # data_script.py:101
+    assert open(p, "rb").read() == ref.getvalue()
+    assert hostio.read_ints_text(p, 11).tolist() == ob.tolist()
+    with pytest.raises(IOError):
+        hostio.read_ints_text(p, 12)                  # short file is an error, not garbage
+
+
+def test_quantize_equals_text_round_trip_and_bin_cache(tmp_path):
+    rs = np.random.RandomState(1)
+    a = rs.uniform(0, 1, (6, 4)) ** 8
+    p = str(tmp_path / "a.txt")
+    hostio.write_matrix_text16(p, a)
+    back = hostio.read_floats_text(p, (6, 4))
+    assert back.dtype == np.float32 and (back == hostio.quantize_text16(a)).all()
+    b = str(tmp_path / "a.f32")
+    hostio.write_bin_f32(b, back)
+    assert (hostio.read_bin_f32(b, 6, 4) == back).all()
+    with pytest.raises(IOError):
+        hostio.read_bin_f32(b, 4, 6)                  # shape is part of the header
+
+
+def test_generator_reproduces_fixture_hashes():
+    g = load_goldens()[0]
+    golden_model(g)        # asserts sha(A), sha(B), sha(Pi), ob against the fixture
+
+
+def test_memory_formula_matches_reference_printout():
+    for g in load_goldens(include_big=True):
+        K, T = g["spec"]["K"], g["spec"]["T"]
+        for r in g["runs"]:
+            assert decoder.reference_memory_bytes(K, T, r["N"], r.get("B", 0)) == r["memory"]
+
+
+@pytest.mark.parametrize("name", ["FLASH_Viterbi_hip", "FLASH_BS_Viterbi_hip"])
+def test_host_program_takes_reference_runpy_patching(name, tmp_path):
+    """Apply the substitutions of the reference's run.py:29-47 to our source and compile it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("run_hip", os.path.join(ROOT, "flash_viterbi_amd", "src", "run_hip.py"))
+    run_hip = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(run_hip)
+    src = open(os.path.join(ROOT, "flash_viterbi_amd", "src", name + ".c")).read()
+    p = {"K_STATE": 77, "T_STATE": 7, "obserRouteLEN": 33, "prob": 0.3, "MAX_THREADS": 3, "BeamSearchWidth": 9}
+    out = run_hip.patch_config(src, name, p)
+    assert "#define K_STATE 77" in out and "#define T_STATE 7\n" in out and "#define obserRouteLEN 33" in out
+    assert "const float prob = 0.3;" in out and "#define MAX_THREADS 3" in out and "prob%.1f" in out
+    if "BS" in name:
+        assert "const int BeamSearchWidth = 9;" in out
+    c = tmp_path / (name + "_modified.c")
+    c.write_text(out)
+    cmd = ["gcc", "-c", "-Wall", "-Werror", "-I", INCLUDE, str(c), "-o", str(tmp_path / "x.o")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr

@@ -211,7 +211,13 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
     FV_HIP(ctx->d_ob.ensure(T));
     FV_HIP(ctx->d_ans.ensure(T));
     FV_HIP(ctx->d_bp.ensure((size_t)T * ctx->K));
-    FV_HIP(ctx->d_rows.ensure(rows_needed * 2 * ctx->K));
+    {
+        const size_t want = rows_needed * 2 * (size_t)ctx->nrows;
+        if (want > ctx->d_rows.n) {
+            FV_HIP(ctx->d_rows.ensure(want));
+            FV_HIP(hipMemsetAsync(ctx->d_rows.p, 0, want * sizeof(float), ctx->stream));   // row pads stay zero
+        }
+    }
     FV_HIP(ctx->d_score.ensure(4));
     FV_HIP(ctx->d_counters.ensure(4));
     if (ctx->comm) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
@@ -246,7 +252,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
         for (int q = 0; q < ch.n; ++q) {
             const fv::Pass &p = passes[base + q];
-            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * K };
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * ctx->nrows };
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
                            ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
@@ -265,9 +271,9 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
             fvk::TaskSlot slots[fvk::MAX_BATCH];
             for (int q = 0; q < nb; ++q) {
                 const fv::Pass &p = passes[base + q];
-                float *r0 = ctx->d_rows.p + (size_t)(base + q) * 2 * K;
-                slots[q].t1_in = r0 + (size_t)((s - 1) & 1) * K;
-                slots[q].t1_out = r0 + (size_t)(s & 1) * K;
+                float *r0 = ctx->d_rows.p + (size_t)(base + q) * 2 * ctx->nrows;
+                slots[q].t1_in = r0 + (size_t)((s - 1) & 1) * ctx->nrows;
+                slots[q].t1_out = r0 + (size_t)(s & 1) * ctx->nrows;
                 slots[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
             }
@@ -290,7 +296,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
     for (int q = 0; q < np; ++q) {
         if (!passes[q].whole) continue;
         const int len = passes[q].R - passes[q].L;
-        const float *last = ctx->d_rows.p + (size_t)q * 2 * K + (size_t)(len & 1) * K;
+        const float *last = ctx->d_rows.p + (size_t)q * 2 * ctx->nrows + (size_t)(len & 1) * ctx->nrows;
         hipLaunchKernelGGL(fvk::final_argmax, dim3(1), dim3(1024), 0, ctx->stream, last, K,
                            ctx->d_ans.p + passes[q].R, ctx->d_score.p);
         FV_HIP(hipGetLastError());

@@ -54,6 +54,8 @@ struct fv_ctx {
     int K = 0, M = 0, nrows = 0;
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
+    DevBuf<unsigned short> LA16;
+    float window16 = 0.0f;   // 2 * max |half(L) - L| over the finite table entries
     DevBuf<double> LA64, LB64T, LPi64;
 
     // workspace
@@ -94,7 +96,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t device_bytes(const fv_ctx *c)
 {
-    return c->LA32.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
+    return c->LA32.bytes() + c->LA16.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes();
@@ -121,16 +123,20 @@ void parallel_rows(int rows, F &&fn)
 int pick_kernel(const fv_ctx *ctx)
 {
     if (ctx->opt_kernel == FV_KERNEL_F64_STREAM) return FV_KERNEL_F64_STREAM;
-    // F32_REFINE's 2-ulp bracket needs every log <= 0 (no cancellation between score and log A)
-    return ctx->logs_nonpositive ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
+    // the filter kernels' error bracket needs every log <= 0 (no cancellation between score and log A)
+    if (!ctx->logs_nonpositive) return FV_KERNEL_F64_STREAM;
+    // binary16 streams half the bytes of float32 (8.0 vs 10.6 us/step before the refine at K=3965) but its
+    // 2^-11 relative spacing makes the window ~0.008 wide: ~430 extra candidates and ~7 lane rescans per
+    // step (19 us/step) against ~14 and 0.3 for float32 (12.3 us/step).  AUTO therefore stays on float32.
+    return ctx->opt_kernel == FV_KERNEL_F16_REFINE ? FV_KERNEL_F16_REFINE : FV_KERNEL_F32_REFINE;
 }
 
-// Kernel variants.  Default: chunks of U 16-byte loads per lane, double-buffered in registers.
+// Kernel variants: chunks of U 16-byte loads per lane, double-buffered in registers.
 // "Upfront" (one register buffer holding the wave's whole share of the tile, requested before the
-// score row is staged) measured SLOWER at K=3965 (16.3 vs 12.9 us/step): with every workgroup's
-// whole tile in flight the L2 lines kept from the previous (opposite-direction) sweep are evicted
-// before they are re-read.  Kept behind FV_OPT_DEBUG bit 2 for experiments.
-constexpr int U_UP32 = 16, U_DB32 = 4, U_DB64 = 2;
+// score row is staged) measured SLOWER for the f32 table at K=3965 (16.3 vs 12.9 us/step): with every
+// workgroup's whole tile in flight the L2 lines kept from the previous (opposite-direction) sweep are
+// evicted before they are re-read.  Kept behind FV_OPT_DEBUG bit 2 for experiments.
+constexpr int U_UP = 16, U_DB32 = 4, U_DB64 = 2, U_DB16 = 2;
 
 template <typename TA, int NB, int U, bool DB>
 int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
@@ -141,10 +147,12 @@ int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
 }
 
 template <typename TA, int NB>
-int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int reverse)
+int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
 {
     fvk::StepArgs<NB> a;
-    a.LA = f32 ? (const void *)ctx->LA32.p : (const void *)ctx->LA64.p;
+    if constexpr (std::is_same<TA, double>::value) { a.LA = ctx->LA64.p; a.window = 0.0f; }
+    else if constexpr (std::is_same<TA, float>::value) { a.LA = ctx->LA32.p; a.window = 0.0f; }
+    else { a.LA = ctx->LA16.p; a.window = ctx->window16; }
     a.LA64 = ctx->LA64.p;
     a.counters = ctx->d_counters.p;
     a.K = ctx->K;
@@ -156,41 +164,60 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, in
     a.nb = nb;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
-    const int nj_max = (ctx->nrows / fvk::RB_ROWS + fvk::NWAVES - 1) / fvk::NWAVES;
-    if constexpr (sizeof(TA) == 4) {
+    constexpr int RBR = 4 * fvk::Tab<TA>::R;
+    const int nj_max = (ctx->nrows / RBR + fvk::NWAVES - 1) / fvk::NWAVES;
+    if constexpr (std::is_same<TA, double>::value) {
+        return launch_variant<TA, NB, U_DB64, true>(ctx, a, lds);
+    } else if constexpr (std::is_same<TA, float>::value) {
         if constexpr (NB <= 2) {
-            if (nj_max <= U_UP32 && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP32, false>(ctx, a, lds);
+            if (nj_max <= U_UP && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
         }
         return launch_variant<TA, NB, U_DB32, true>(ctx, a, lds);
     } else {
-        return launch_variant<TA, NB, U_DB64, true>(ctx, a, lds);
+        if constexpr (NB <= 2) {
+            if (nj_max <= U_UP && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
+        }
+        return launch_variant<TA, NB, U_DB16, true>(ctx, a, lds);
     }
 }
 
 template <typename TA>
-int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, bool f32, int reverse)
+int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
 {
-    if (nb <= 1) return launch_step_nb<TA, 1>(ctx, slots, nb, f32, reverse);
-    if (nb <= 2) return launch_step_nb<TA, 2>(ctx, slots, nb, f32, reverse);
-    if (nb <= 4) return launch_step_nb<TA, 4>(ctx, slots, nb, f32, reverse);
-    return launch_step_nb<TA, 8>(ctx, slots, nb, f32, reverse);
+    if (nb <= 1) return launch_step_nb<TA, 1>(ctx, slots, nb, reverse);
+    if (nb <= 2) return launch_step_nb<TA, 2>(ctx, slots, nb, reverse);
+    if (nb <= 4) return launch_step_nb<TA, 4>(ctx, slots, nb, reverse);
+    return launch_step_nb<TA, 8>(ctx, slots, nb, reverse);
+}
+
+int launch_step_kernel(fv_ctx *ctx, int kernel, const fvk::TaskSlot *slots, int nb, int reverse)
+{
+    switch (kernel) {
+    case FV_KERNEL_F64_STREAM: return launch_step<double>(ctx, slots, nb, reverse);
+    case FV_KERNEL_F32_REFINE: return launch_step<float>(ctx, slots, nb, reverse);
+    default: return launch_step<fvk::half_t>(ctx, slots, nb, reverse);
+    }
+}
+
+template <typename K>
+int set_big_lds(fv_ctx *ctx, K kernel)
+{
+    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
 }
 
 template <typename TA, int NB>
 int allow_big_lds(fv_ctx *ctx)
 {
-    const int big = 160 * 1024;
-    if constexpr (sizeof(TA) == 4) {
-        if constexpr (NB <= 2)
-            FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_UP32, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_DB32, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    int rc = 0;
+    if constexpr (std::is_same<TA, double>::value) {
+        rc = set_big_lds(ctx, &fvk::trellis_step<TA, NB, U_DB64, true>);
     } else {
-        FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_step<TA, NB, U_DB64, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        constexpr int U = std::is_same<TA, float>::value ? U_DB32 : U_DB16;
+        rc = set_big_lds(ctx, &fvk::trellis_step<TA, NB, U, true>);
+        if constexpr (NB <= 2) { if (!rc) rc = set_big_lds(ctx, &fvk::trellis_step<TA, NB, U_UP, false>); }
     }
-    return 0;
+    return rc;
 }
 
 // largest batch whose score rows fit LDS next to the reduction scratch
@@ -239,7 +266,7 @@ int prof_event(fv_ctx *ctx, size_t idx, hipEvent_t *out)
 
 // Runs every pass of one generation in lock-step: at lock-step s each still-active pass advances
 // from time L+s-1 to L+s.  Passes are sorted longest first so the active set is a prefix.
-int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, size_t &nprof)
+int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, size_t &nprof)
 {
     const int K = ctx->K;
     const int np = (int)passes.size();
@@ -284,7 +311,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, bool f32, si
                 nprof += 2;
                 FV_HIP(hipEventRecord(e0, ctx->stream));
             }
-            int rc = f32 ? launch_step<float>(ctx, slots, nb, true, s & 1) : launch_step<double>(ctx, slots, nb, false, s & 1);
+            int rc = launch_step_kernel(ctx, kernel, slots, nb, s & 1);
             if (rc) return rc;
             if (ctx->opt_profile) FV_HIP(hipEventRecord(e1, ctx->stream));
             ctx->stats.step_launches += 1;
@@ -392,7 +419,9 @@ extern "C" int fv_create(fv_ctx **out, int device)
     int rc = 0;
     if ((rc = allow_big_lds<float, 1>(ctx)) || (rc = allow_big_lds<float, 2>(ctx)) || (rc = allow_big_lds<float, 4>(ctx)) ||
         (rc = allow_big_lds<float, 8>(ctx)) || (rc = allow_big_lds<double, 1>(ctx)) || (rc = allow_big_lds<double, 2>(ctx)) ||
-        (rc = allow_big_lds<double, 4>(ctx)) || (rc = allow_big_lds<double, 8>(ctx)))
+        (rc = allow_big_lds<double, 4>(ctx)) || (rc = allow_big_lds<double, 8>(ctx)) ||
+        (rc = allow_big_lds<fvk::half_t, 1>(ctx)) || (rc = allow_big_lds<fvk::half_t, 2>(ctx)) ||
+        (rc = allow_big_lds<fvk::half_t, 4>(ctx)) || (rc = allow_big_lds<fvk::half_t, 8>(ctx)))
         return fail(rc);
     if ((rc = fvb::allow_big_lds(ctx->detail))) return fail(rc);
     *out = ctx;
@@ -405,7 +434,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
-    ctx->LA32.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
+    ctx->LA32.release(); ctx->LA16.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release();
@@ -424,14 +453,16 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     if (!ctx || !A || !B || !Pi || K < 1 || M < 1) return FV_ERR_ARG;
     auto t0 = clk::now();
     FV_HIP(hipSetDevice(ctx->device));
-    const int nrows = round_up(K, fvk::RB_ROWS);
+    const int nrows = round_up(K, fvk::ROW_ALIGN);
     const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
     if (fvk::step_lds_bytes<1>(nrows) > 160 * 1024) return FV_ERR_UNSUPPORTED;   // one score row must fit LDS
 
     const size_t tab = (size_t)ntiles * nrows * fvk::TILE_W;
     std::vector<double> h64;
     std::vector<float> h32;
-    try { h64.assign(tab, -HUGE_VAL); h32.assign(tab, -HUGE_VALF); } catch (...) { return FV_ERR_NOMEM; }
+    std::vector<unsigned short> h16;
+    try { h64.assign(tab, -HUGE_VAL); h32.assign(tab, -HUGE_VALF); h16.assign(tab, 0xFC00u /* -inf */); } catch (...) { return FV_ERR_NOMEM; }
+    std::vector<double> dmax_row(K, 0.0);
     bool ok_range = true;
     std::vector<char> bad(K, 0), big(K, 0);
     parallel_rows(K, [&](int a, int b) {
@@ -442,8 +473,18 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
                 if (!(x >= 0.0f) || std::isinf(x)) bad[k] = 1;
                 if (x > 1.0f) big[k] = 1;
                 const double l = std::log((double)x);
-                const size_t e = fvk::tab_index(k, i, nrows);
+                const size_t e = fvk::tab_index<4>(k, i, nrows);
                 h64[e] = l; h32[e] = (float)l;
+                const _Float16 hl = (_Float16)l;          // round to nearest even; -inf stays -inf
+                unsigned short hb;
+                std::memcpy(&hb, &hl, 2);
+                h16[fvk::tab_index<8>(k, i, nrows)] = hb;
+                if (std::isfinite(l)) {
+                    // a finite log that overflows binary16 (< -65504) would become -inf: cannot happen for
+                    // float32 inputs (log >= -104), but keep the bound honest
+                    const double d = std::isfinite((double)hl) ? std::fabs((double)hl - l) : HUGE_VAL;
+                    if (d > dmax_row[k]) dmax_row[k] = d;
+                }
             }
         }
     });
@@ -466,8 +507,13 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     for (int k = 0; k < K; ++k) { if (bad[k]) ok_range = false; if (big[k]) any_big = true; }
     if (!ok_range) { ctx->detail = "model entries must be finite and >= 0"; return FV_ERR_ARG; }
 
+    double dmax = 0.0;
+    for (int k = 0; k < K; ++k) dmax = std::max(dmax, dmax_row[k]);
+    ctx->window16 = std::nextafter((float)(2.0 * dmax), HUGE_VALF);     // rounded up
     FV_HIP(ctx->LA64.ensure(tab));
     FV_HIP(ctx->LA32.ensure(tab));
+    FV_HIP(ctx->LA16.ensure(tab));
+    FV_HIP(hipMemcpy(ctx->LA16.p, h16.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
     FV_HIP(ctx->LB64T.ensure((size_t)M * K));
     FV_HIP(ctx->LB32T.ensure((size_t)M * K));
     FV_HIP(ctx->LPi64.ensure(K));
@@ -489,7 +535,7 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
     if (!ctx) return FV_ERR_ARG;
     switch (key) {
     case FV_OPT_KERNEL:
-        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_F32_REFINE) return FV_ERR_ARG;
+        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_F16_REFINE) return FV_ERR_ARG;
         ctx->opt_kernel = (int)value; return FV_OK;
     case FV_OPT_MAX_BATCH:
         if (value < 1 || value > fvk::MAX_BATCH) return FV_ERR_ARG;
@@ -507,8 +553,8 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
-    if (ctx->opt_kernel == FV_KERNEL_F32_REFINE && !ctx->logs_nonpositive) {
-        ctx->detail = "FV_KERNEL_F32_REFINE needs every model entry in [0,1]";
+    if ((ctx->opt_kernel == FV_KERNEL_F32_REFINE || ctx->opt_kernel == FV_KERNEL_F16_REFINE) && !ctx->logs_nonpositive) {
+        ctx->detail = "the filter+refine kernels need every model entry in [0,1]";
         return FV_ERR_UNSUPPORTED;
     }
     auto t0 = clk::now();
@@ -516,7 +562,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     fv::Plan plan;
     int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
     if (rc) return rc;
-    const bool f32 = pick_kernel(ctx) == FV_KERNEL_F32_REFINE;
+    const int kernel = pick_kernel(ctx);
 
     // generations of passes this rank runs
     std::vector<std::vector<fv::Pass>> gens(plan.generations());
@@ -529,9 +575,9 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     const double keep_model_ms = ctx->stats.set_model_ms;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = keep_model_ms;
-    ctx->stats.kernel = f32 ? FV_KERNEL_F32_REFINE : FV_KERNEL_F64_STREAM;
+    ctx->stats.kernel = kernel;
     ctx->stats.generations = plan.generations();
-    ctx->stats.table_bytes_per_step = (long long)((ctx->K + fvk::TILE_W - 1) / fvk::TILE_W) * ctx->nrows * fvk::TILE_W * (f32 ? 4 : 8);
+    ctx->stats.table_bytes_per_step = (long long)((ctx->K + fvk::TILE_W - 1) / fvk::TILE_W) * ctx->nrows * fvk::TILE_W * (kernel == FV_KERNEL_F64_STREAM ? 8 : kernel == FV_KERNEL_F32_REFINE ? 4 : 2);
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -541,7 +587,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     size_t nprof = 0;
     for (size_t g = 0; g < gens.size(); ++g) {
         ctx->stats.passes += (int)gens[g].size();
-        if ((rc = run_generation_full(ctx, gens[g], f32, nprof))) return rc;
+        if ((rc = run_generation_full(ctx, gens[g], kernel, nprof))) return rc;
         if (g == 0) FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream));
     }
     ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * ctx->K;

@@ -60,6 +60,9 @@ enum {
     FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim */
     FV_KERNEL_F32_REFINE = 2,  /* streams (float)log A (4 B/cell), brackets the winner within 2 ulp,
                                   then re-evaluates the few candidates in float64: same bits out */
+    FV_KERNEL_F16_REFINE = 3,  /* same scheme with log A rounded to binary16 (2 B/cell) and a window of
+                                  2*max|half(L)-L| + 3 ulp: same bits out, a quarter of the float64 bytes; the wider
+                                  window costs more refines than the bytes save at K=3965 */
 };
 
 typedef struct {
@@ -75,8 +78,8 @@ typedef struct {
     long long alg_bytes;      /* 4 bytes per cell */
     long long table_bytes_per_step; /* bytes of transition table one step launch streams */
     long long device_bytes;   /* device working set (tables + workspace) */
-    long long refine_near;    /* F32_REFINE: candidates within 2 ulp of a column's best */
-    long long refine_rescan;  /* F32_REFINE: lanes that had to rescan their rows */
+    long long refine_near;    /* filter kernels: candidates inside the window besides a column's best */
+    long long refine_rescan;  /* filter kernels: lanes that had to rescan their rows */
     int passes;               /* forward passes run (reference mode: one per right-hand task) */
     int generations;          /* dependent batches of passes */
     int kernel;               /* FV_KERNEL_* actually used */

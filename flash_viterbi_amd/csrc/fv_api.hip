@@ -63,8 +63,11 @@ struct fv_ctx {
     DevBuf<float> d_rows, d_score;
     DevBuf<unsigned long long> d_counters;
     // beam workspace
-    DevBuf<float> d_hval, d_scores;
-    DevBuf<int> d_hstate, d_flags;
+    DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
+    DevBuf<int> d_hstate, d_slot_state, d_flags;
+    DevBuf<double> LA64R;                            // row-gather copy of the float64 table (built on first beam decode)
+    DevBuf<int2> d_tie_list;
+    DevBuf<unsigned int> d_tie_count;
 
     // options
     int opt_kernel = FV_KERNEL_AUTO;
@@ -99,7 +102,8 @@ size_t device_bytes(const fv_ctx *c)
     return c->LA32.bytes() + c->LA16.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
-           c->d_hstate.bytes() + c->d_flags.bytes();
+           c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
+           c->LA64R.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -388,6 +392,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     }
     st.refine_near = (long long)counters[0];
     st.refine_rescan = (long long)counters[1];
+    st.beam_exact_sets = (long long)counters[2];
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
     bool neg = false;
@@ -437,7 +442,8 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->LA32.release(); ctx->LA16.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
-    ctx->d_hstate.release(); ctx->d_flags.release();
+    ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
+    ctx->LA64R.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -523,6 +529,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->K = K; ctx->M = M; ctx->nrows = nrows;
+    ctx->LA64R.release();                 // rebuilt from the new table on the next beam decode
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = ms_since(t0);
@@ -597,57 +604,67 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
 
 namespace {
 
-// One generation of beam passes in lock-step (same shape as run_generation_full).
-int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam)
+// One generation of beam passes in lock-step (same shape as run_generation_full).  Buffers are indexed
+// by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
+// scores after consuming ob[j] (j = L: the init row), set_*[j] = the members of the heap built from
+// them (order-free), slot_*[j] = its exact array layout (rebuilt after the lock-step loop).
+int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, int T)
 {
     const int K = ctx->K, np = (int)passes.size();
     if (np == 0) return 0;
     std::stable_sort(passes.begin(), passes.end(),
                      [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
-    auto scores_of = [&](int q) { return ctx->d_scores.p + (size_t)q * K; };
-    auto hval_of = [&](int q, int par) { return ctx->d_hval.p + ((size_t)q * 2 + par) * beam; };
-    auto hstate_of = [&](int q, int par) { return ctx->d_hstate.p + ((size_t)q * 2 + par) * beam; };
-    auto build_heaps = [&](int count, int par) -> int {
+    const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
+    auto scores_at = [&](int j) { return ctx->d_scores.p + (size_t)j * K; };
+    auto setv_at = [&](int j) { return ctx->d_hval.p + (size_t)j * beam; };
+    auto sets_at = [&](int j) { return ctx->d_hstate.p + (size_t)j * beam; };
+    FV_HIP(hipMemsetAsync(ctx->d_tie_count.p, 0, sizeof(unsigned int), ctx->stream));
+    auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s
         for (int base = 0; base < count; base += fvb::BEAM_CHUNK) {
-            fvb::HeapArgs h;
-            h.K = K; h.beam = beam; h.n = std::min(fvb::BEAM_CHUNK, count - base);
-            for (int q = 0; q < h.n; ++q) h.p[q] = fvb::HeapJob{ scores_of(base + q), hval_of(base + q, par), hstate_of(base + q, par) };
-            hipLaunchKernelGGL(fvb::heap_build, dim3(h.n), dim3(64), fvb::heap_lds(beam), ctx->stream, h);
+            fvb::SelArgs a;
+            a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.n = std::min(fvb::BEAM_CHUNK, count - base);
+            for (int q = 0; q < a.n; ++q) {
+                const int j = passes[base + q].L + s;
+                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j) };
+            }
+            hipLaunchKernelGGL(fvb::topb_select, dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
             FV_HIP(hipGetLastError());
         }
         return 0;
     };
-    // init scores (the same rows the full variant starts from, FLASH_BS:407-427), then the first heaps
+    // init scores (the same rows the full variant starts from, FLASH_BS:407-427), then the first heaps' members
     for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
         fvk::PassChunk ch;
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
         for (int q = 0; q < ch.n; ++q) {
             const fv::Pass &p = passes[base + q];
-            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * K };
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)p.L * K };
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
                            ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
                            ctx->d_scores.p, K);
         FV_HIP(hipGetLastError());
     }
-    int rc = build_heaps(np, 0);
+    int rc = select(np, 0);
     if (rc) return rc;
     const int maxlen = passes[0].R - passes[0].L;
-    const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
     int active = np;
     for (int s = 1; s <= maxlen; ++s) {
         while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
         for (int base = 0; base < active; base += fvb::BEAM_CHUNK) {
             fvb::BeamStepArgs a;
-            a.LA64 = ctx->LA64.p; a.K = K; a.nrows = ctx->nrows; a.beam = beam; a.ntiles = ntiles;
+            a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
+            a.tie_cap = (unsigned int)ctx->d_tie_list.n;
+            a.K = K; a.nrows = ctx->nrows; a.beam = beam; a.ntiles = ntiles;
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
-                const fv::Pass &p = passes[base + q];
-                a.p[q].hval = hval_of(base + q, (s - 1) & 1);
-                a.p[q].hstate = hstate_of(base + q, (s - 1) & 1);
-                a.p[q].scores = scores_of(base + q);
-                a.p[q].bp_row = ctx->d_bp.p + (size_t)(p.L + s) * K;
-                a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
+                const int j = passes[base + q].L + s;
+                a.p[q].sval = setv_at(j - 1);
+                a.p[q].sstate = sets_at(j - 1);
+                a.p[q].scores = scores_at(j);
+                a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
+                a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
+                a.p[q].j = j;
             }
             hipLaunchKernelGGL(fvb::beam_step, dim3(ntiles, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
                                ctx->stream, a);
@@ -655,20 +672,39 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam)
             ctx->stats.step_launches += 1;
             ctx->stats.task_steps += a.n;
         }
-        if ((rc = build_heaps(active, s & 1))) return rc;
+        if ((rc = select(active, s))) return rc;
+    }
+    // off the critical path: exact layouts of every step's heap, tie fix-up, pass ends
+    for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
+        fvb::HeapAllArgs h;
+        h.scores_all = ctx->d_scores.p; h.slot_val = ctx->d_slot_val.p; h.slot_state = ctx->d_slot_state.p;
+        h.K = K; h.beam = beam; h.n = std::min(fvb::BEAM_CHUNK, np - base);
+        int longest = 0;
+        for (int q = 0; q < h.n; ++q) {
+            h.p[q] = fvb::HeapRange{ passes[base + q].L, passes[base + q].R };
+            longest = std::max(longest, passes[base + q].R - passes[base + q].L + 1);
+        }
+        hipLaunchKernelGGL(fvb::heap_build_all, dim3(longest, h.n), dim3(64), fvb::heap_lds(beam), ctx->stream, h);
+        FV_HIP(hipGetLastError());
+    }
+    {
+        fvb::FixArgs f;
+        f.LA64R = ctx->LA64R.p; f.LB32T = ctx->LB32T.p; f.ob = ctx->d_ob.p;
+        f.tie_count = ctx->d_tie_count.p; f.tie_list = ctx->d_tie_list.p; f.tie_cap = (unsigned int)ctx->d_tie_list.n;
+        f.slot_val = ctx->d_slot_val.p; f.slot_state = ctx->d_slot_state.p; f.bp = ctx->d_bp.p;
+        f.K = K; f.nrows = ctx->nrows; f.beam = beam;
+        hipLaunchKernelGGL(fvb::tie_fixup, dim3(512), dim3(256), 0, ctx->stream, f);
+        FV_HIP(hipGetLastError());
     }
     for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
         fvb::BeamEndArgs e;
         e.K = K; e.beam = beam; e.n = std::min(fvb::BEAM_CHUNK, np - base);
-        for (int q = 0; q < e.n; ++q) {
-            const fv::Pass &p = passes[base + q];
-            const int par = (p.R - p.L) & 1;
-            e.p[q] = fvb::BeamEnd{ p.L, p.R, p.whole ? 1 : 0, hval_of(base + q, par), hstate_of(base + q, par) };
-        }
-        hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_bp.p,
-                           ctx->d_ans.p, ctx->d_score.p);
+        for (int q = 0; q < e.n; ++q) e.p[q] = fvb::BeamEnd{ passes[base + q].L, passes[base + q].R, passes[base + q].whole ? 1 : 0 };
+        hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_slot_val.p,
+                           ctx->d_slot_state.p, ctx->d_bp.p, ctx->d_ans.p, ctx->d_score.p);
         FV_HIP(hipGetLastError());
     }
+    (void)T;
     return 0;
 }
 
@@ -681,7 +717,7 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     if (ctx->K == 0) return FV_ERR_STATE;
     // beam > K reads uninitialised heap slots in the reference
     if (beam_width < 2 || beam_width > ctx->K) return FV_ERR_ARG;
-    if (fvb::beam_step_lds(beam_width) > 160 * 1024 || fvb::heap_lds(beam_width) > 160 * 1024) return FV_ERR_UNSUPPORTED;
+    if (fvb::beam_step_lds(beam_width) > 150 * 1024 || fvb::heap_lds(beam_width) > 150 * 1024) return FV_ERR_UNSUPPORTED;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     auto t0 = clk::now();
     FV_HIP(hipSetDevice(ctx->device));
@@ -694,9 +730,20 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
         if (p.owner < 0 || p.owner % ctx->nranks == ctx->rank) gens[p.generation].push_back(p);
     for (auto &g : gens) most = std::max(most, g.size());
     if ((rc = ensure_workspace(ctx, T, 1))) return rc;
-    FV_HIP(ctx->d_scores.ensure(most * ctx->K));
-    FV_HIP(ctx->d_hval.ensure(most * 2 * beam_width));
-    FV_HIP(ctx->d_hstate.ensure(most * 2 * beam_width));
+    (void)most;
+    FV_HIP(ctx->d_scores.ensure((size_t)T * ctx->K));
+    FV_HIP(ctx->d_hval.ensure((size_t)T * beam_width));
+    FV_HIP(ctx->d_hstate.ensure((size_t)T * beam_width));
+    FV_HIP(ctx->d_slot_val.ensure((size_t)T * beam_width));
+    FV_HIP(ctx->d_slot_state.ensure((size_t)T * beam_width));
+    FV_HIP(ctx->d_tie_list.ensure((size_t)T * ctx->K));
+    FV_HIP(ctx->d_tie_count.ensure(4));
+    if (!ctx->LA64R.p) {
+        const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
+        FV_HIP(ctx->LA64R.ensure((size_t)ntiles * ctx->nrows * fvk::TILE_W));
+        hipLaunchKernelGGL(fvb::relayout_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LA64R.p, ctx->nrows, ntiles);
+        FV_HIP(hipGetLastError());
+    }
 
     const double keep_model_ms = ctx->stats.set_model_ms;
     ctx->stats = fv_stats{};
@@ -713,7 +760,7 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     for (size_t g = 0; g < gens.size(); ++g) {
         ctx->stats.passes += (int)gens[g].size();
-        if ((rc = run_generation_beam(ctx, gens[g], beam_width))) return rc;
+        if ((rc = run_generation_beam(ctx, gens[g], beam_width, T))) return rc;
         if (g == 0) { FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream)); FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream)); }
     }
     ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * beam_width;

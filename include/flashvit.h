@@ -80,6 +80,8 @@ typedef struct {
     long long device_bytes;   /* device working set (tables + workspace) */
     long long refine_near;    /* filter kernels: candidates inside the window besides a column's best */
     long long refine_rescan;  /* filter kernels: lanes that had to rescan their rows */
+    long long beam_exact_sets;/* FLASH-BS: steps whose heap members needed the exact replay (duplicate scores at the cut) */
+    long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order */
     int passes;               /* forward passes run (reference mode: one per right-hand task) */
     int generations;          /* dependent batches of passes */
     int kernel;               /* FV_KERNEL_* actually used */

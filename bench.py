@@ -163,7 +163,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"FLASH Viterbi full-state decode K={K} T={T} M={M} prob={PROB} seed={SEED} "
                                    f"n_split={N_SPLIT} mode=reference (BASELINE configs[1])",
-                       "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine"}[st["kernel"]],
+                       "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine"}[st["kernel"]],
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
                        "parallelism": f"segments over {args.gpus} rank(s)"},
             "decode_ms": 1e3 * dt / args.steps,
@@ -172,7 +172,7 @@ def main():
             "single_pass_mode_ms": ps["gpu_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>", 3: "fvk::trellis_step<fvk::half_t,1,2,true>"}[st["kernel"]], "launch_us": launch_us,
+                         "kernel": {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>", 3: "fvk::trellis_step<fvk::half_t,1,2,true>", 4: "fvk::trellis_step<fvk::q16_t,1,2,true>"}[st["kernel"]], "launch_us": launch_us,
                          "alg_bytes_per_launch": alg_bytes_per_launch, "launches_per_decode": T - 1,
                          "table_bytes_streamed_per_launch": ps["table_bytes_per_step"]},
         }

@@ -54,8 +54,9 @@ struct fv_ctx {
     int K = 0, M = 0, nrows = 0;
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
-    DevBuf<unsigned short> LA16;
+    DevBuf<unsigned short> LA16, LAQ16;
     float window16 = 0.0f;   // 2 * max |half(L) - L| over the finite table entries
+    float windowq = 0.0f, qscale = -1.0f;   // same for the fixed-point table; value = code * qscale
     DevBuf<double> LA64, LB64T, LPi64;
 
     // workspace
@@ -99,7 +100,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t device_bytes(const fv_ctx *c)
 {
-    return c->LA32.bytes() + c->LA16.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
+    return c->LA32.bytes() + c->LA16.bytes() + c->LAQ16.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
@@ -132,7 +133,8 @@ int pick_kernel(const fv_ctx *ctx)
     // binary16 streams half the bytes of float32 (8.0 vs 10.6 us/step before the refine at K=3965) but its
     // 2^-11 relative spacing makes the window ~0.008 wide: ~430 extra candidates and ~7 lane rescans per
     // step (19 us/step) against ~14 and 0.3 for float32 (12.3 us/step).  AUTO therefore stays on float32.
-    return ctx->opt_kernel == FV_KERNEL_F16_REFINE ? FV_KERNEL_F16_REFINE : FV_KERNEL_F32_REFINE;
+    if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_Q16_REFINE) return ctx->opt_kernel;
+    return FV_KERNEL_F32_REFINE;
 }
 
 // Kernel variants: chunks of U 16-byte loads per lane, double-buffered in registers.
@@ -156,7 +158,9 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     fvk::StepArgs<NB> a;
     if constexpr (std::is_same<TA, double>::value) { a.LA = ctx->LA64.p; a.window = 0.0f; }
     else if constexpr (std::is_same<TA, float>::value) { a.LA = ctx->LA32.p; a.window = 0.0f; }
+    else if constexpr (std::is_same<TA, fvk::q16_t>::value) { a.LA = ctx->LAQ16.p; a.window = ctx->windowq; }
     else { a.LA = ctx->LA16.p; a.window = ctx->window16; }
+    a.qscale = ctx->qscale;
     a.LA64 = ctx->LA64.p;
     a.counters = ctx->d_counters.p;
     a.K = ctx->K;
@@ -199,6 +203,7 @@ int launch_step_kernel(fv_ctx *ctx, int kernel, const fvk::TaskSlot *slots, int 
     switch (kernel) {
     case FV_KERNEL_F64_STREAM: return launch_step<double>(ctx, slots, nb, reverse);
     case FV_KERNEL_F32_REFINE: return launch_step<float>(ctx, slots, nb, reverse);
+    case FV_KERNEL_Q16_REFINE: return launch_step<fvk::q16_t>(ctx, slots, nb, reverse);
     default: return launch_step<fvk::half_t>(ctx, slots, nb, reverse);
     }
 }
@@ -426,7 +431,9 @@ extern "C" int fv_create(fv_ctx **out, int device)
         (rc = allow_big_lds<float, 8>(ctx)) || (rc = allow_big_lds<double, 1>(ctx)) || (rc = allow_big_lds<double, 2>(ctx)) ||
         (rc = allow_big_lds<double, 4>(ctx)) || (rc = allow_big_lds<double, 8>(ctx)) ||
         (rc = allow_big_lds<fvk::half_t, 1>(ctx)) || (rc = allow_big_lds<fvk::half_t, 2>(ctx)) ||
-        (rc = allow_big_lds<fvk::half_t, 4>(ctx)) || (rc = allow_big_lds<fvk::half_t, 8>(ctx)))
+        (rc = allow_big_lds<fvk::half_t, 4>(ctx)) || (rc = allow_big_lds<fvk::half_t, 8>(ctx)) ||
+        (rc = allow_big_lds<fvk::q16_t, 1>(ctx)) || (rc = allow_big_lds<fvk::q16_t, 2>(ctx)) ||
+        (rc = allow_big_lds<fvk::q16_t, 4>(ctx)) || (rc = allow_big_lds<fvk::q16_t, 8>(ctx)))
         return fail(rc);
     if ((rc = fvb::allow_big_lds(ctx->detail))) return fail(rc);
     *out = ctx;
@@ -439,7 +446,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
-    ctx->LA32.release(); ctx->LA16.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
+    ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
@@ -516,6 +523,35 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     double dmax = 0.0;
     for (int k = 0; k < K; ++k) dmax = std::max(dmax, dmax_row[k]);
     ctx->window16 = std::nextafter((float)(2.0 * dmax), HUGE_VALF);     // rounded up
+    // fixed-point table: step = (largest finite |log A|) / 65534, code = round(-L/step), 0xffff = -inf.
+    // The kernel evaluates fma(code, -step, s) with step as a float, so the error is measured against
+    // exactly that product (code * (double)(float)step is exact in double).
+    std::vector<unsigned short> hq;
+    try { hq.assign(tab, 0xFFFFu); } catch (...) { return FV_ERR_NOMEM; }
+    double lmax = 0.0;
+    for (size_t e = 0; e < tab; ++e) if (std::isfinite(h64[e])) lmax = std::max(lmax, -h64[e]);
+    const float stepf = lmax > 0.0 ? (float)(lmax / 65534.0) : 1.0f;
+    const double stepd = (double)stepf;
+    std::vector<double> dq_row(K, 0.0);
+    parallel_rows(K, [&](int a, int b) {
+        for (int k = a; k < b; ++k)
+            for (int i = 0; i < K; ++i) {
+                const double l = h64[fvk::tab_index<4>(k, i, nrows)];
+                if (!std::isfinite(l)) continue;
+                double q = std::nearbyint(-l / stepd);
+                if (q < 0) q = 0;
+                if (q > 65534.0) q = 65534.0;
+                hq[fvk::tab_index<8>(k, i, nrows)] = (unsigned short)q;
+                const double d = std::fabs(-q * stepd - l);
+                if (d > dq_row[k]) dq_row[k] = d;
+            }
+    });
+    double dqmax = 0.0;
+    for (int k = 0; k < K; ++k) dqmax = std::max(dqmax, dq_row[k]);
+    ctx->windowq = std::nextafter((float)(2.0 * dqmax), HUGE_VALF);
+    ctx->qscale = -stepf;
+    FV_HIP(ctx->LAQ16.ensure(tab));
+    FV_HIP(hipMemcpy(ctx->LAQ16.p, hq.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
     FV_HIP(ctx->LA64.ensure(tab));
     FV_HIP(ctx->LA32.ensure(tab));
     FV_HIP(ctx->LA16.ensure(tab));
@@ -542,7 +578,7 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
     if (!ctx) return FV_ERR_ARG;
     switch (key) {
     case FV_OPT_KERNEL:
-        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_F16_REFINE) return FV_ERR_ARG;
+        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_Q16_REFINE) return FV_ERR_ARG;
         ctx->opt_kernel = (int)value; return FV_OK;
     case FV_OPT_MAX_BATCH:
         if (value < 1 || value > fvk::MAX_BATCH) return FV_ERR_ARG;
@@ -560,7 +596,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
-    if ((ctx->opt_kernel == FV_KERNEL_F32_REFINE || ctx->opt_kernel == FV_KERNEL_F16_REFINE) && !ctx->logs_nonpositive) {
+    if (ctx->opt_kernel >= FV_KERNEL_F32_REFINE && !ctx->logs_nonpositive) {
         ctx->detail = "the filter+refine kernels need every model entry in [0,1]";
         return FV_ERR_UNSUPPORTED;
     }

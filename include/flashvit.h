@@ -63,6 +63,8 @@ enum {
     FV_KERNEL_F16_REFINE = 3,  /* same scheme with log A rounded to binary16 (2 B/cell) and a window of
                                   2*max|half(L)-L| + 3 ulp: same bits out, a quarter of the float64 bytes; the wider
                                   window costs more refines than the bytes save at K=3965 */
+    FV_KERNEL_Q16_REFINE = 4,  /* same scheme with 16-bit fixed point (step = max|log A|/65534): 2 B/cell and
+                                  a window ~ step: same bits out */
 };
 
 typedef struct {

@@ -12,7 +12,7 @@ from flash_viterbi_amd import decoder
 pytestmark = pytest.mark.gpu
 
 PAIRS, IDS = golden_runs(include_big=True, algo="flash")
-KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE]
+KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE, decoder.KERNEL_Q16_REFINE]
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +31,7 @@ def ctxs():
         fv.close()
 
 
-@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine", "f16refine"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine", "f16refine", "q16refine"])
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_reference_mode_matches_golden(ctxs, g, r, kernel):
     fv, ob = ctxs(g)

@@ -172,7 +172,7 @@ def main():
             "single_pass_mode_ms": ps["gpu_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>", 3: "fvk::trellis_step<fvk::half_t,1,2,true>", 4: "fvk::trellis_step<fvk::q16_t,1,2,true>"}[st["kernel"]], "launch_us": launch_us,
+                         "kernel": {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>", 3: "fvk::trellis_step<fvk::half_t,1,2,true>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>"}[st["kernel"]], "launch_us": launch_us,
                          "alg_bytes_per_launch": alg_bytes_per_launch, "launches_per_decode": T - 1,
                          "table_bytes_streamed_per_launch": ps["table_bytes_per_step"]},
         }

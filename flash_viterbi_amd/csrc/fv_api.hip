@@ -130,11 +130,11 @@ int pick_kernel(const fv_ctx *ctx)
     if (ctx->opt_kernel == FV_KERNEL_F64_STREAM) return FV_KERNEL_F64_STREAM;
     // the filter kernels' error bracket needs every log <= 0 (no cancellation between score and log A)
     if (!ctx->logs_nonpositive) return FV_KERNEL_F64_STREAM;
-    // binary16 streams half the bytes of float32 (8.0 vs 10.6 us/step before the refine at K=3965) but its
-    // 2^-11 relative spacing makes the window ~0.008 wide: ~430 extra candidates and ~7 lane rescans per
-    // step (19 us/step) against ~14 and 0.3 for float32 (12.3 us/step).  AUTO therefore stays on float32.
-    if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_Q16_REFINE) return ctx->opt_kernel;
-    return FV_KERNEL_F32_REFINE;
+    // Measured at K=3965 (us per step of the whole-sequence pass): q16 9.5, f32 11.1, f16 12.8, f64 20.7.
+    // binary16's 2^-11 relative spacing makes its window ~0.008 wide (~430 extra candidates and ~7 lane
+    // rescans per step); 16-bit fixed point has a window of ~3e-4 (~21 and 0.4) at the same 2 B/cell.
+    if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_F32_REFINE) return ctx->opt_kernel;
+    return FV_KERNEL_Q16_REFINE;
 }
 
 // Kernel variants: chunks of U 16-byte loads per lane, double-buffered in registers.
@@ -182,8 +182,10 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
         }
         return launch_variant<TA, NB, U_DB32, true>(ctx, a, lds);
     } else {
+        // 16-bit tables: an XCD's slab (3.9 MB at K=3965) nearly fits its L2, so requesting the whole
+        // tile before staging the score row wins (9.5 vs 9.8 us/step); FV_OPT_DEBUG bit 2 turns it off
         if constexpr (NB <= 2) {
-            if (nj_max <= U_UP && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
+            if (nj_max <= U_UP && !(ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
         }
         return launch_variant<TA, NB, U_DB16, true>(ctx, a, lds);
     }
@@ -297,19 +299,24 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     }
     const int maxlen = passes[0].R - passes[0].L;
     const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows)));
-    int active = np;
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
+    const bool col_last = !(ctx->opt_debug & 8);  // FV_OPT_DEBUG bit 3: run every last step as a full step
     if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
+    // passes are sorted longest first: at lock-step s the passes with len >= s are a prefix; those with
+    // len == s are finishing and (unless they are the whole-sequence pass) only need one column
+    int active = np;
     for (int s = 1; s <= maxlen; ++s) {
         while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
-        for (int base = 0; base < active; base += cap) {
-            const int nb = std::min(cap, active - base);
+        int full = active;                           // passes [0, full) take a full step
+        if (col_last) while (full > 0 && passes[full - 1].R - passes[full - 1].L == s && !passes[full - 1].whole) --full;
+        auto row = [&](int q, int parity) { return ctx->d_rows.p + (size_t)q * 2 * ctx->nrows + (size_t)parity * ctx->nrows; };
+        for (int base = 0; base < full; base += cap) {
+            const int nb = std::min(cap, full - base);
             fvk::TaskSlot slots[fvk::MAX_BATCH];
             for (int q = 0; q < nb; ++q) {
                 const fv::Pass &p = passes[base + q];
-                float *r0 = ctx->d_rows.p + (size_t)(base + q) * 2 * ctx->nrows;
-                slots[q].t1_in = r0 + (size_t)((s - 1) & 1) * ctx->nrows;
-                slots[q].t1_out = r0 + (size_t)(s & 1) * ctx->nrows;
+                slots[q].t1_in = row(base + q, (s - 1) & 1);
+                slots[q].t1_out = row(base + q, s & 1);
                 slots[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
             }
@@ -325,6 +332,19 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
             if (ctx->opt_profile) FV_HIP(hipEventRecord(e1, ctx->stream));
             ctx->stats.step_launches += 1;
             ctx->stats.task_steps += nb;
+        }
+        for (int base = full; base < active; base += fvk::COL_CHUNK) {
+            fvk::ColArgs c;
+            c.LA64 = ctx->LA64.p; c.ans = ctx->d_ans.p; c.K = K; c.nrows = ctx->nrows;
+            c.n = std::min(fvk::COL_CHUNK, active - base);
+            for (int q = 0; q < c.n; ++q) {
+                const fv::Pass &p = passes[base + q];
+                c.p[q] = fvk::ColJob{ row(base + q, (s - 1) & 1), ctx->LB32T.p + (size_t)ctx->h_ob[p.R] * K,
+                                      ctx->d_bp.p + (size_t)p.R * K, p.R };
+            }
+            hipLaunchKernelGGL(fvk::last_column, dim3(c.n), dim3(256), 0, ctx->stream, c);
+            FV_HIP(hipGetLastError());
+            ctx->stats.column_steps += c.n;
         }
     }
     if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream));
@@ -633,7 +653,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
         if ((rc = run_generation_full(ctx, gens[g], kernel, nprof))) return rc;
         if (g == 0) FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream));
     }
-    ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * ctx->K;
+    ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * ctx->K + ctx->stats.column_steps * (long long)ctx->K;
     ctx->stats.alg_bytes = 4 * ctx->stats.cells;
     return finish_decode(ctx, plan, T, path_out, score_out, t0, nprof, false);
 }

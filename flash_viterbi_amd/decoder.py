@@ -24,6 +24,7 @@ class Stats(ctypes.Structure):
                 ("top_pass_ms", ctypes.c_double), ("top_steps_ms", ctypes.c_double),
                 ("step_kernel_ms", ctypes.c_double),
                 ("step_launches", ctypes.c_longlong), ("task_steps", ctypes.c_longlong),
+                ("column_steps", ctypes.c_longlong),
                 ("cells", ctypes.c_longlong), ("alg_bytes", ctypes.c_longlong),
                 ("table_bytes_per_step", ctypes.c_longlong), ("device_bytes", ctypes.c_longlong),
                 ("refine_near", ctypes.c_longlong), ("refine_rescan", ctypes.c_longlong),

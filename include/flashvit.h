@@ -56,7 +56,7 @@ enum {
     FV_OPT_DEBUG = 100,     /* kernel-tuning switches for timing experiments only (bit0 voids results) */
 };
 enum {
-    FV_KERNEL_AUTO = 0,        /* F32_REFINE when every model entry is in [0,1], else F64_STREAM */
+    FV_KERNEL_AUTO = 0,        /* Q16_REFINE when every model entry is in [0,1], else F64_STREAM */
     FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim */
     FV_KERNEL_F32_REFINE = 2,  /* streams (float)log A (4 B/cell), brackets the winner within 2 ulp,
                                   then re-evaluates the few candidates in float64: same bits out */
@@ -75,8 +75,9 @@ typedef struct {
     double top_steps_ms;      /* HIP-event time around generation 0's T-1 back-to-back step launches only */
     double step_kernel_ms;    /* sum of per-launch event times of the step kernel (FV_OPT_PROFILE=1) */
     long long step_launches;  /* trellis-step kernel launches in the last decode */
-    long long task_steps;     /* sum over launches of tasks advanced (= passes' total step count) */
-    long long cells;          /* add-compare cells: task_steps * K * K (full) or * K * beam */
+    long long task_steps;     /* sum over launches of tasks advanced by a full K*K (or K*beam) step */
+    long long column_steps;   /* last steps of passes evaluated for the one destination column the back-track reads */
+    long long cells;          /* add-compare cells: task_steps * K * K + column_steps * K (full) or task_steps * K * beam */
     long long alg_bytes;      /* 4 bytes per cell */
     long long table_bytes_per_step; /* bytes of transition table one step launch streams */
     long long device_bytes;   /* device working set (tables + workspace) */

@@ -113,3 +113,19 @@ def test_argument_errors():
     with pytest.raises(decoder.FlashVitError):
         fv.set_model(bad, A[:, :2] * 2, A[0])
     fv.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine", "f16refine", "q16refine"])
+@pytest.mark.parametrize("bits", [2, 4, 8, 2 | 4 | 8], ids=["noreverse", "altloads", "fulllast", "all"])
+def test_tuning_switches_do_not_change_results(ctxs, kernel, bits):
+    """Sweep direction, load schedule and the single-column last step are speed knobs only."""
+    pairs = [(g, r) for g, r in PAIRS if g["name"] in ("cfg2_K3965_T256", "ties_semi_K96_T80", "ds_K200_T100")]
+    for g, r in pairs:
+        fv, ob = ctxs(g)
+        fv.set_option(decoder.OPT_KERNEL, kernel)
+        fv.set_option(decoder.OPT_DEBUG, bits)
+        try:
+            path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])

@@ -51,7 +51,13 @@ int fvh_quantize_text16(const double *in, float *out, size_t n)
 int fvh_write_matrix_text16(const char *path, const double *a, size_t rows, size_t cols,
                             int row_newline)
 {
-    FILE *fp = fopen(path, "wb");
+    return fvh_write_matrix_text16_ex(path, a, rows, cols, row_newline, 0);
+}
+
+int fvh_write_matrix_text16_ex(const char *path, const double *a, size_t rows, size_t cols,
+                               int row_newline, int append)
+{
+    FILE *fp = fopen(path, append ? "ab" : "wb");
     if (!fp) return FVH_ERR_OPEN;
     char *io = (char *)malloc(FVH_IOBUF);
     if (!io) { fclose(fp); return FVH_ERR_NOMEM; }

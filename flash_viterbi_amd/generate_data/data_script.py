@@ -20,7 +20,9 @@ Deliberate differences:
     output, ~20x faster at K=3965 (a 299 MB file);
   * --bin also writes raw float32 caches (`*.f32`, `ob_*.i32`) holding exactly
     the floats the reference's fscanf("%f") loader would obtain from the text;
-  * -o chooses the output directory (the reference writes to the cwd).
+  * -o chooses the output directory (the reference writes to the cwd);
+  * --stream (automatic for K >= 16384) produces and writes A in row blocks, byte-identical to the dense
+    route, so K = 65536 (34 GB as float64, ~82 GB as text) never has to fit in memory.
 """
 import getopt
 import os
@@ -30,7 +32,7 @@ import sys
 import numpy as np
 
 USAGE = ("data_script.py -s <seed> -n <n_ob> -K <K> -T <T> -b <beam_width> -p <prob> "
-         "[-o <out_dir>] [--ob-seed <seed>] [--bin] [--no-text]")
+         "[-o <out_dir>] [--ob-seed <seed>] [--bin] [--no-text] [--stream]")
 
 
 def make_transition(K, seed, prob):
@@ -45,6 +47,53 @@ def make_transition(K, seed, prob):
     for src in range(K):
         A[src, :] = A[src, :] / np.sum(A[src, :])
     return A
+
+
+def stream_transition(K, seed, prob, block_rows=512):
+    """Yields (first_row, float64 block) of the same matrix make_transition returns, block_rows rows at a
+    time.  The reference draws every row's edges first and normalises afterwards (data_script.py:11-32),
+    but only the draws consume the RNG and the normalisation is row-local, so producing row by row gives
+    the same numbers; the row sum is still taken over the dense K-entry row (np.sum's pairwise order)."""
+    np.random.seed(seed)
+    for r0 in range(0, K, block_rows):
+        n = min(block_rows, K - r0)
+        blk = np.zeros((n, K), dtype=np.float64)
+        for q in range(n):
+            n_edges = np.random.binomial(K, p=prob, size=None)
+            dst = np.random.choice(K, size=n_edges, replace=False)
+            blk[q, dst] = np.random.uniform(0.01, 1, size=n_edges)
+        for q in range(n):
+            blk[q, :] = blk[q, :] / np.sum(blk[q, :])
+        yield r0, blk
+
+
+def write_files_streaming(out_dir, K, n_ob, T, prob, seed, ob, text=True, binary=True, block_rows=512):
+    """write_files for models too large to hold as float64 (K = 65536: 34 GB): A is produced and written
+    in row blocks; B, Pi, ob are small."""
+    from flash_viterbi_amd import hostio
+    os.makedirs(out_dir, exist_ok=True)
+    p = lambda kind, ext: os.path.join(out_dir, file_stem(kind, K, T, prob) + ext)
+    fbin = None
+    if binary:
+        fbin = open(p("A", ".f32"), "wb")
+        fbin.write(hostio.bin_header(1, K, K))
+    for r0, blk in stream_transition(K, seed, prob, block_rows):
+        if text:
+            hostio.append_matrix_text16(p("A", ".txt"), blk, first=(r0 == 0))
+        if fbin:
+            fbin.write(hostio.quantize_text16(blk).tobytes())
+    if fbin:
+        fbin.close()
+    B = make_emission(K, n_ob, seed)
+    Pi = np.full(K, 1 / K)
+    if text:
+        hostio.write_matrix_text16(p("B", ".txt"), B)
+        hostio.write_vector_text16(p("Pi", ".txt"), Pi)
+        hostio.write_ints_text(p("ob", ".txt"), ob)
+    if binary:
+        hostio.write_bin_f32(p("B", ".f32"), hostio.quantize_text16(B))
+        hostio.write_bin_f32(p("Pi", ".f32"), hostio.quantize_text16(Pi).reshape(1, -1))
+        hostio.write_bin_i32(p("ob", ".i32"), np.asarray(ob, dtype=np.int32).reshape(1, -1))
 
 
 def make_emission(K, n_ob, seed):
@@ -86,12 +135,12 @@ def write_files(out_dir, K, T, prob, A, B, Pi, ob, text=True, binary=False):
 
 def main(argv):
     try:
-        opts, _ = getopt.getopt(argv, "hs:n:K:T:b:p:o:", ["ob-seed=", "bin", "no-text"])
+        opts, _ = getopt.getopt(argv, "hs:n:K:T:b:p:o:", ["ob-seed=", "bin", "no-text", "stream"])
     except getopt.GetoptError:
         print(USAGE)
         sys.exit(2)
     got = {}
-    out_dir, ob_seed, binary, text = ".", None, False, True
+    out_dir, ob_seed, binary, text, stream = ".", None, False, True, False
     for opt, arg in opts:
         if opt == "-h":
             print(USAGE)
@@ -108,6 +157,8 @@ def main(argv):
             binary = True
         elif opt == "--no-text":
             text = False
+        elif opt == "--stream":
+            stream = True
     if len(got) != 6:
         print(USAGE)
         sys.exit(2)
@@ -118,6 +169,9 @@ def main(argv):
     with open(os.path.join(out_dir, f"ANS_K{K}_T{T}_prob{prob}_beam_width{beam}.txt"), "w") as f:
         f.write(f"sd={sd}, n_ob={n_ob}, K={K}, T={T}, beam_width={beam}, prob={prob}\n")
     ob = make_observations(T, n_ob, sd if ob_seed is None else ob_seed)
+    if stream or K >= 16384:
+        write_files_streaming(out_dir, K, n_ob, T, prob, sd, ob, text=text, binary=binary)
+        return
     A, B, Pi = make_model64(K, n_ob, sd, prob)
     write_files(out_dir, K, T, prob, A, B, Pi, ob, text=text, binary=binary)
 

@@ -22,6 +22,7 @@ def lib():
         vp = ctypes.c_void_p
         L.fvh_quantize_text16.argtypes = [vp, vp, sz]
         L.fvh_write_matrix_text16.argtypes = [cp, vp, sz, sz, ci]
+        L.fvh_write_matrix_text16_ex.argtypes = [cp, vp, sz, sz, ci, ci]
         L.fvh_write_ints_text.argtypes = [cp, vp, sz]
         L.fvh_read_floats_text.argtypes = [cp, vp, sz]
         L.fvh_read_ints_text.argtypes = [cp, vp, sz]
@@ -54,6 +55,20 @@ def write_matrix_text16(path, a64):
     a64 = np.ascontiguousarray(a64, dtype=np.float64)
     assert a64.ndim == 2
     _check(lib().fvh_write_matrix_text16(path.encode(), _ptr(a64), a64.shape[0], a64.shape[1], 1), path)
+
+
+def append_matrix_text16(path, a64, first):
+    """Row block of a matrix written by write_matrix_text16, appended (first=True truncates)."""
+    a64 = np.ascontiguousarray(a64, dtype=np.float64)
+    assert a64.ndim == 2
+    _check(lib().fvh_write_matrix_text16_ex(path.encode(), _ptr(a64), a64.shape[0], a64.shape[1], 1, 0 if first else 1), path)
+
+
+BIN_MAGIC = 0x31425646
+
+
+def bin_header(dtype_code, rows, cols):
+    return np.array([BIN_MAGIC, dtype_code, rows, cols], dtype=np.uint32).tobytes()
 
 
 def write_vector_text16(path, v64):

@@ -39,6 +39,10 @@ int fvh_quantize_text16(const double *in, float *out, size_t n);
  * written with newline=' ' (data_script.py:100). */
 int fvh_write_matrix_text16(const char *path, const double *a, size_t rows, size_t cols,
                             int row_newline);
+/* Same, appending to an existing file when append != 0: lets a generator emit a K x K matrix in row
+ * blocks without ever holding it (K = 65536 would be 34 GB of float64). */
+int fvh_write_matrix_text16_ex(const char *path, const double *a, size_t rows, size_t cols,
+                               int row_newline, int append);
 /* np.savetxt(path, v, fmt='%d', newline=' ') (data_script.py:101). */
 int fvh_write_ints_text(const char *path, const int *v, size_t n);
 

@@ -130,3 +130,19 @@ def test_host_program_takes_reference_runpy_patching(name, tmp_path):
     cmd = ["gcc", "-c", "-Wall", "-Werror", "-I", INCLUDE, str(c), "-o", str(tmp_path / "x.o")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_streaming_generator_is_byte_identical_to_dense(tmp_path):
+    from flash_viterbi_amd.generate_data import data_script
+    K, M, T, prob, seed = 150, 9, 20, 0.2, 4
+    ob = data_script.make_observations(T, M, seed)
+    A, B, Pi = data_script.make_model64(K, M, seed, prob)
+    d1, d2 = str(tmp_path / "dense"), str(tmp_path / "stream")
+    data_script.write_files(d1, K, T, prob, A, B, Pi, ob, text=True, binary=True)
+    data_script.write_files_streaming(d2, K, M, T, prob, seed, ob, text=True, binary=True, block_rows=37)
+    names = sorted(os.listdir(d1))
+    assert names == sorted(os.listdir(d2)) and len(names) == 8
+    for n in names:
+        assert open(os.path.join(d1, n), "rb").read() == open(os.path.join(d2, n), "rb").read(), n
+    back = hostio.read_bin_f32(os.path.join(d2, f"A_K{K}_T{T}_prob{prob}.f32"), K, K)
+    assert (back == hostio.quantize_text16(A)).all()

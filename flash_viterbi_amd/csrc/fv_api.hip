@@ -74,6 +74,7 @@ struct fv_ctx {
     int opt_kernel = FV_KERNEL_AUTO;
     int opt_max_batch = fvk::MAX_BATCH;
     int opt_profile = 0;
+    int vanilla = 0;         // set for the duration of fv_decode_vanilla
     int opt_debug = 0;       // FV_OPT_DEBUG bits: 1 skip refine (timing only), 2 no reverse sweep, 4 alternate unroll
     std::vector<hipEvent_t> prof_events;
     std::vector<int> h_ob;
@@ -161,6 +162,7 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     else if constexpr (std::is_same<TA, fvk::q16_t>::value) { a.LA = ctx->LAQ16.p; a.window = ctx->windowq; }
     else { a.LA = ctx->LA16.p; a.window = ctx->window16; }
     a.qscale = ctx->qscale;
+    a.vanilla = ctx->vanilla;
     a.LA64 = ctx->LA64.p;
     a.counters = ctx->d_counters.p;
     a.K = ctx->K;
@@ -318,6 +320,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                 slots[q].t1_in = row(base + q, (s - 1) & 1);
                 slots[q].t1_out = row(base + q, s & 1);
                 slots[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
+                slots[q].tmp64_row = ctx->LB64T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
             }
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -822,6 +825,18 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * beam_width;
     ctx->stats.alg_bytes = 4 * ctx->stats.cells;
     return finish_decode(ctx, plan, T, path_out, score_out, t0, 0, true);
+}
+
+extern "C" int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_out, float *score_out)
+{
+    if (!ctx) return FV_ERR_ARG;
+    const int keep_kernel = ctx->opt_kernel;
+    ctx->opt_kernel = FV_KERNEL_F64_STREAM;      // the baseline's expression has no filter form
+    ctx->vanilla = 1;
+    int rc = fv_decode_full(ctx, ob, T, 1, FV_MODE_SINGLE_PASS, path_out, score_out);
+    ctx->vanilla = 0;
+    ctx->opt_kernel = keep_kernel;
+    return rc;
 }
 
 extern "C" int fv_last_stats(const fv_ctx *ctx, fv_stats *out)

@@ -41,6 +41,7 @@ class PassInfo(ctypes.Structure):
 
 
 EXPORTS = ["fv_create", "fv_destroy", "fv_set_model", "fv_set_option", "fv_decode_full", "fv_decode_beam",
+           "fv_decode_vanilla",
            "fv_last_stats", "fv_strerror", "fv_last_error_detail", "fv_reference_memory_bytes",
            "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths"]
 
@@ -65,6 +66,7 @@ def load_library():
     L.fv_set_option.argtypes = [vp, ci, cll]
     L.fv_decode_full.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.fv_decode_beam.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
+    L.fv_decode_vanilla.argtypes = [vp, vp, ci, vp, vp]
     L.fv_last_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.fv_strerror.argtypes = [ci]
     L.fv_strerror.restype = ctypes.c_char_p
@@ -166,6 +168,13 @@ class FlashViterbi:
         path = np.empty(ob.size, dtype=np.int32)
         score = ctypes.c_float(0)
         rc = self._check(self._L.fv_decode_beam(self._h, _p(ob), ob.size, n_split, beam, mode, _p(path), ctypes.byref(score)))
+        return path, np.float32(score.value), rc
+
+    def decode_vanilla(self, ob):
+        ob = np.ascontiguousarray(ob, dtype=np.int32)
+        path = np.empty(ob.size, dtype=np.int32)
+        score = ctypes.c_float(0)
+        rc = self._check(self._L.fv_decode_vanilla(self._h, _p(ob), ob.size, _p(path), ctypes.byref(score)))
         return path, np.float32(score.value), rc
 
     def stats(self):

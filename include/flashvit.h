@@ -115,6 +115,14 @@ int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, int mode,
 int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode,
                    int *path_out, float *score_out);
 
+/* GPU form of the reference's baseline programs Base_line/C implementations/vanilla Viterbi.c:125-173 and
+ * checkpoint Viterbi.c (same recurrence, hence the same output): one forward pass with the BASELINE's
+ * rounding order, tmp2 = (float)(((double)T1[k] + log A[k][i]) + log B[i][o]) (:140), lowest-index
+ * end state, plain back-track.  An independent cross-check of the FLASH paths (its scores may differ from
+ * FLASH's in the last ulp, its path equals FLASH's on every fixture) and the measure of what the
+ * divide-and-conquer schedule costs on a device where T*K back-pointers fit trivially. */
+int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_out, float *score_out);
+
 int fv_last_stats(const fv_ctx *ctx, fv_stats *out);
 const char *fv_strerror(int rc);
 const char *fv_last_error_detail(const fv_ctx *ctx);

@@ -22,9 +22,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SRC = "/root/reference/src"
+REF_BASE = "/root/reference/Base_line/C implementations"
 OUT = os.path.join(HERE, "_ref")
 
-SOURCES = {"flash": "FLASH_Viterbi_multithread.c", "flashbs": "FLASH_BS_Viterbi_multithread.c"}
+SOURCES = {"flash": "FLASH_Viterbi_multithread.c", "flashbs": "FLASH_BS_Viterbi_multithread.c",
+           "vanilla": "vanilla Viterbi.c"}
+
+
+def source_path(kind):
+    return os.path.join(REF_BASE if kind == "vanilla" else REF_SRC, SOURCES[kind])
 # gcc flags exactly as reference src/run.py:54
 GCC = ["gcc", "-g", "-pthread", "-x", "c", "-", "-lm", "-Wl,-z,stack-size=268435456"]
 
@@ -41,7 +47,7 @@ def ref_name(kind, K, T, prob, N, beam=None, M=50, score=False):
 
 
 def reference_available():
-    return all(os.path.isfile(os.path.join(REF_SRC, f)) for f in SOURCES.values())
+    return all(os.path.isfile(source_path(k)) for k in SOURCES)
 
 
 def _patch(text, kind, K, T, prob, N, beam, M, score):
@@ -55,14 +61,17 @@ def _patch(text, kind, K, T, prob, N, beam, M, score):
     text = sub1(r"#define obserRouteLEN \d+", f"#define obserRouteLEN {T}", text)
     text = sub1(r"const float prob = \d+\.\d+;", f"const float prob = {prob};", text)
     text = sub1(r'const char data_path\[\] = "[^"]*";', 'const char data_path[] = "./";', text)
-    text = sub1(r"#define MAX_THREADS \d+", f"#define MAX_THREADS {N}", text)
+    if kind != "vanilla":
+        text = sub1(r"#define MAX_THREADS \d+", f"#define MAX_THREADS {N}", text)
     if kind == "flashbs":
         text = sub1(r"const int BeamSearchWidth = \d+;", f"const int BeamSearchWidth = {beam};", text)
     digits = len(str(prob).split(".")[1]) if "." in str(prob) else 0
     text = sub1(r"prob%\.\d+f", f"prob%.{digits}f", text)
     if score:
         # after the whole-sequence end-state pick ("vit->Ans[R] = arg;" / "... .State;")
-        if kind == "flash":
+        if kind == "vanilla":
+            text = sub1(r"(vit->Ans\[obserRouteLEN-1\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)tmp);', text)
+        elif kind == "flash":
             text = sub1(r"(vit->Ans\[R\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)score);', text)
         else:
             text = sub1(r"(vit->Ans\[R\] = H\[cur\](?:\[1\])?\[arg\+1\]\.State;)",
@@ -79,7 +88,7 @@ def build(kind, K, T, prob, N, beam=None, M=50, score=False, force=False):
         return exe
     if not reference_available():
         raise FileNotFoundError(f"{exe} not prebuilt and {REF_SRC} is absent")
-    with open(os.path.join(REF_SRC, SOURCES[kind]), "r") as f:
+    with open(source_path(kind), "r") as f:
         text = _patch(f.read(), kind, K, T, prob, N, beam, M, score)
     res = subprocess.run(GCC + ["-o", exe], input=text, text=True, capture_output=True)
     if res.returncode != 0:

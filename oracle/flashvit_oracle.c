@@ -300,6 +300,52 @@ int fvo_full_forward(const fvo_model *m, const int *ob, int L, int R, int init_s
     return 0;
 }
 
+/* --------------------------------------------------------------- vanilla -- */
+
+/* viterbi() of Base_line/C implementations/vanilla Viterbi.c:125-173.  Different rounding order from
+ * FLASH: tmp2 = (float)( ((double)T1[k][j-1] + log A[k][i]) + log B[i][ob[j]] ) — two double adds, one
+ * rounding (:140); end state from (-FLT_MAX, -1) with strict '>' (:153-162). */
+int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, float *score)
+{
+    if (!m || !ob || !path || T < 1) return FVO_ERR_ARG;
+    for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= m->M) return FVO_ERR_ARG;
+    const int K = m->K, M = m->M;
+    float *a = (float *)malloc(sizeof(float) * K), *b = (float *)malloc(sizeof(float) * K);
+    int *T2 = (int *)malloc(sizeof(int) * (size_t)K * T);
+    if (!a || !b || !T2) { free(a); free(b); free(T2); return FVO_ERR_NOMEM; }
+    full_init_row(m, ob[0], -1, a);
+    int rc = 0;
+    for (int j = 1; j < T; ++j) {
+        const int o = ob[j];
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < K; ++i) {
+            const double *col = m->logAT + (size_t)i * K;
+            const double lb = m->logB[(size_t)i * M + o];
+            float tmp = -FLT_MAX;
+            int arg = -1;
+            for (int k = 0; k < K; ++k) {
+                float tmp2 = (float)(((double)a[k] + col[k]) + lb);
+                if (tmp2 > tmp) { tmp = tmp2; arg = k; }
+            }
+            b[i] = tmp;
+            T2[(size_t)j * K + i] = arg;
+        }
+        float *t = a; a = b; b = t;
+    }
+    float tmp = -FLT_MAX;
+    int arg = -1;
+    for (int i = 0; i < K; ++i) if (a[i] > tmp) { tmp = a[i]; arg = i; }
+    if (arg < 0) rc = FVO_ERR_NO_PRED;
+    path[T - 1] = arg;
+    for (int j = T - 1; j > 0 && !rc; --j) {
+        path[j - 1] = T2[(size_t)j * K + path[j]];
+        if (path[j - 1] < 0) rc = FVO_ERR_NO_PRED;
+    }
+    if (score) *score = tmp;
+    free(a); free(b); free(T2);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ beam -- */
 
 /* FLASH_BS:51-56.  Slot 0's .value carries the element count as a float. */

@@ -47,6 +47,10 @@ int fvo_full_decode(const fvo_model *m, const int *ob, int T, int n_split,
 int fvo_beam_decode(const fvo_model *m, const int *ob, int T, int n_split, int beam,
                     int *path, float *score, long long *cells);
 
+/* viterbi() of the reference's baseline Base_line/C implementations/vanilla Viterbi.c:125-173 (also the
+ * output of its checkpoint Viterbi.c: same recurrence, different memory schedule). */
+int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, float *score);
+
 /* One plain forward pass over [L,R] (nvviter's recurrence, :204-246) that keeps
  * every arg row: score_row[K] = T1 after the last step, argtab[(R-L)*K] = arg of
  * step j at row j-L-1 (-1 where no finite predecessor).  init_state < 0 => start

@@ -46,6 +46,7 @@ def lib():
         L.fvo_full_decode.argtypes = [vp, vp, ci, ci, vp, vp, vp]
         L.fvo_beam_decode.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp]
         L.fvo_full_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+        L.fvo_vanilla_decode.argtypes = [vp, vp, ci, vp, vp]
         L.fvo_set_threads.argtypes = [ci]
         L.fvo_full_memory_bytes.restype = ctypes.c_longlong
         L.fvo_full_memory_bytes.argtypes = [ci, ci, ci]
@@ -111,6 +112,15 @@ class OracleModel:
         if rc < 0 and check:
             raise OracleError(rc)
         return path, np.float32(score.value), cells.value, rc
+
+    def vanilla_decode(self, ob, check=True):
+        ob = np.ascontiguousarray(ob, dtype=np.int32)
+        path = np.empty(ob.size, dtype=np.int32)
+        score = ctypes.c_float(0)
+        rc = lib().fvo_vanilla_decode(self._h, _p(ob), ob.size, _p(path), ctypes.byref(score))
+        if rc < 0 and check:
+            raise OracleError(rc)
+        return path, np.float32(score.value), rc
 
     def full_forward(self, ob, L, R, init_state=-1):
         ob = np.ascontiguousarray(ob, dtype=np.int32)

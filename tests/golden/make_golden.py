@@ -33,27 +33,28 @@ OB_CFG2 = [int(x) for x in """15 16 18 9 27 30 26 28 18 19 41 23 18 14 16 25 26 
 
 F = lambda *ns: [dict(algo="flash", N=n) for n in ns]
 BS = lambda *nb: [dict(algo="flashbs", N=n, B=b) for n, b in nb]
+V = [dict(algo="vanilla", N=1)]     # Base_line/C implementations/vanilla Viterbi.c (cross-check baseline)
 
 CASES = [
     dict(name="cfg1_K128_T256", spec=dict(kind="data_script", K=128, M=50, T=256, prob=0.253, seed=12, ob=OB_CFG1),
-         runs=F(1, 4, 8) + BS((1, 32), (2, 32), (3, 32), (4, 32), (8, 32), (16, 32), (4, 64), (4, 128))),
+         runs=F(1, 4, 8) + BS((1, 32), (2, 32), (3, 32), (4, 32), (8, 32), (16, 32), (4, 64), (4, 128)) + V),
     dict(name="ds_K200_T100", spec=dict(kind="data_script", K=200, M=50, T=100, prob=0.1, seed=3),
-         runs=F(1, 3, 5, 7) + BS((1, 16), (3, 17), (5, 50), (4, 200))),
+         runs=F(1, 3, 5, 7) + BS((1, 16), (3, 17), (5, 50), (4, 200)) + V),
     dict(name="ds_K77_M7_T33", spec=dict(kind="data_script", K=77, M=7, T=33, prob=0.3, seed=5),
-         runs=F(1, 2, 3, 4) + BS((1, 8), (3, 9), (4, 77))),
+         runs=F(1, 2, 3, 4) + BS((1, 8), (3, 9), (4, 77)) + V),
     dict(name="ds_K512_T64", spec=dict(kind="data_script", K=512, M=50, T=64, prob=0.05, seed=7),
          runs=F(1, 8) + BS((8, 64), (1, 100))),
-    dict(name="ds_K5_T2", spec=dict(kind="data_script", K=5, M=3, T=2, prob=0.9, seed=1), runs=F(1) + BS((1, 2), (1, 5))),
+    dict(name="ds_K5_T2", spec=dict(kind="data_script", K=5, M=3, T=2, prob=0.9, seed=1), runs=F(1) + BS((1, 2), (1, 5)) + V),
     dict(name="ds_K5_T3", spec=dict(kind="data_script", K=5, M=3, T=3, prob=0.9, seed=2), runs=F(1, 2) + BS((1, 3))),
     dict(name="ds_K9_T7", spec=dict(kind="data_script", K=9, M=3, T=7, prob=0.8, seed=4), runs=F(1, 3) + BS((1, 4), (3, 4))),
     dict(name="ties_all_K64_T64", spec=dict(kind="ties_all", K=64, M=4, T=64, prob=0.5, seed=21),
-         runs=F(1, 4) + BS((1, 8), (4, 16), (3, 64))),
+         runs=F(1, 4) + BS((1, 8), (4, 16), (3, 64)) + V),
     dict(name="ties_semi_K96_T80", spec=dict(kind="ties_semi", K=96, M=4, T=80, prob=0.5, seed=22),
-         runs=F(1, 3, 8) + BS((1, 12), (4, 32), (8, 33))),
+         runs=F(1, 3, 8) + BS((1, 12), (4, 32), (8, 33)) + V),
 ]
 BIG_CASES = [
     dict(name="cfg2_K3965_T256", spec=dict(kind="data_script", K=3965, M=50, T=256, prob=0.112, seed=12, ob=OB_CFG2),
-         runs=F(8) + BS((8, 32), (8, 256))),
+         runs=F(8) + BS((8, 32), (8, 256)) + V),
 ]
 
 

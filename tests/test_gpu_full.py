@@ -129,3 +129,30 @@ def test_tuning_switches_do_not_change_results(ctxs, kernel, bits):
         finally:
             fv.set_option(decoder.OPT_DEBUG, 0)
         assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+
+
+VPAIRS, VIDS = golden_runs(include_big=True, algo="vanilla")
+
+
+@pytest.mark.parametrize("g,r", VPAIRS, ids=VIDS)
+def test_vanilla_baseline_matches_reference_vanilla_binary(ctxs, g, r):
+    """fv_decode_vanilla against goldens from Base_line/C implementations/vanilla Viterbi.c."""
+    fv, ob = ctxs(g)
+    path, score, rc = fv.decode_vanilla(ob)
+    assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+
+
+def test_vanilla_matches_oracle_and_flash_path_on_fresh_input():
+    import modelgen
+    spec = dict(kind="data_script", K=700, M=13, T=90, prob=0.1, seed=301)
+    A, B, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, B, Pi)
+    vp, vs, _ = om.vanilla_decode(ob)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    path, score, rc = fv.decode_vanilla(ob)
+    assert path.tolist() == vp.tolist() and score == vs
+    fpath, fscore, _ = fv.decode_full(ob, 8)
+    assert fpath.tolist() == path.tolist()          # same optimum, possibly last-ulp different score
+    assert abs(float(fscore) - float(score)) <= 1e-5 * abs(float(score))
+    fv.close()

@@ -15,7 +15,10 @@ def test_oracle_matches_reference_binary(g, r):
     A, B, Pi, ob = golden_model(g)
     m = oracle.OracleModel(A, B, Pi)
     T = len(ob)
-    if r["algo"] == "flash":
+    if r["algo"] == "vanilla":
+        path, score, rc = m.vanilla_decode(ob)
+        mem = m.K * T * 8        # sizeof(T1)+sizeof(T2), vanilla Viterbi.c:172
+    elif r["algo"] == "flash":
         path, score, cells, rc = m.full_decode(ob, r["N"])
         mem = oracle.full_memory_bytes(m.K, T, r["N"])
     else:

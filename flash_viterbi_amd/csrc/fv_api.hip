@@ -904,6 +904,14 @@ extern "C" int fv_comm_unique_id(void *id_out)
     return FV_OK;
 }
 
+extern "C" int fv_set_partition(fv_ctx *ctx, int rank, int nranks)
+{
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks) return FV_ERR_ARG;
+    if (ctx->comm) return FV_ERR_STATE;
+    ctx->rank = rank; ctx->nranks = nranks;
+    return FV_OK;
+}
+
 extern "C" int fv_comm_init(fv_ctx *ctx, int rank, int nranks, const void *id)
 {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return FV_ERR_ARG;

@@ -43,7 +43,7 @@ class PassInfo(ctypes.Structure):
 EXPORTS = ["fv_create", "fv_destroy", "fv_set_model", "fv_set_option", "fv_decode_full", "fv_decode_beam",
            "fv_decode_vanilla",
            "fv_last_stats", "fv_strerror", "fv_last_error_detail", "fv_reference_memory_bytes",
-           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths"]
+           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths", "fv_set_partition"]
 
 _lib = None
 
@@ -76,6 +76,7 @@ def load_library():
     L.fv_reference_memory_bytes.restype = cll
     L.fv_comm_unique_id.argtypes = [vp]
     L.fv_comm_init.argtypes = [vp, ci, ci, vp]
+    L.fv_set_partition.argtypes = [vp, ci, ci]
     L.fv_plan_passes.argtypes = [ci, ci, ci, ci, ctypes.POINTER(PassInfo), ci]
     L.fv_merge_paths.argtypes = [ci, ci, ci, vp, vp]
     _lib = L
@@ -181,6 +182,9 @@ class FlashViterbi:
         s = Stats()
         self._check(self._L.fv_last_stats(self._h, ctypes.byref(s)))
         return s.as_dict()
+
+    def set_partition(self, rank, nranks):
+        self._check(self._L.fv_set_partition(self._h, rank, nranks))
 
     def comm_init(self, rank, nranks, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)

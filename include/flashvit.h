@@ -141,6 +141,13 @@ long long fv_reference_memory_bytes(int K, int T, int n_split, int beam_width);
 int fv_comm_unique_id(void *id_out);
 int fv_comm_init(fv_ctx *ctx, int rank, int nranks, const void *id);
 
+/* Sharding without a communicator: the decode calls run the whole-sequence pass plus only the
+ * segments rank `rank` of `nranks` owns and return that rank's answer array (positions owned by other
+ * ranks hold the whole-pass chain); the caller gathers the nranks arrays by its own means and applies
+ * fv_merge_paths.  For hosts that already have a collective layer (bench.py falls back to this with
+ * torch.distributed if fv_comm_init fails). */
+int fv_set_partition(fv_ctx *ctx, int rank, int nranks);
+
 /* The merge applied after the all-gather, exposed for CPU tests: gathered = nranks arrays of T
  * answers (rank-major); position j is taken from the rank owning the top-level segment that
  * contains it, segment end points from rank 0. */

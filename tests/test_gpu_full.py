@@ -156,3 +156,27 @@ def test_vanilla_matches_oracle_and_flash_path_on_fresh_input():
     assert fpath.tolist() == path.tolist()          # same optimum, possibly last-ulp different score
     assert abs(float(fscore) - float(score)) <= 1e-5 * abs(float(score))
     fv.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_partitioned_decode_merges_to_single_rank_result(ctxs, nranks):
+    """fv_set_partition: each 'rank' (here: contexts on one GPU, one after the other) decodes the
+    whole-sequence pass plus its own segments; fv_merge_paths of the per-rank arrays equals the
+    single-rank decode.  Full and beam variants."""
+    g = next(g for g, r in PAIRS if g["name"] == "cfg1_K128_T256")
+    A, B, Pi, ob = golden_model(g)
+    want_full = next(r for r in g["runs"] if r["algo"] == "flash" and r["N"] == 8)["path"]
+    want_beam = next(r for r in g["runs"] if r["algo"] == "flashbs" and r["N"] == 8 and r["B"] == 32)["path"]
+    parts_full, parts_beam = [], []
+    for rank in range(nranks):
+        fv = decoder.FlashViterbi(0)
+        fv.set_model(A, B, Pi)
+        fv.set_partition(rank, nranks)
+        parts_full.append(fv.decode_full(ob, 8)[0])
+        parts_beam.append(fv.decode_beam(ob, 8, 32)[0])
+        st = fv.stats()
+        assert st["ranks"] == nranks and st["passes"] < 127      # 127 passes in all at T=256, N=8
+        fv.close()
+    T = len(ob)
+    assert decoder.merge_paths(T, 8, nranks, np.stack(parts_full)).tolist() == want_full
+    assert decoder.merge_paths(T, 8, nranks, np.stack(parts_beam)).tolist() == want_beam

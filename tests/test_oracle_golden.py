@@ -7,7 +7,7 @@ import pytest
 import oracle
 from conftest import golden_model, golden_runs
 
-PAIRS, IDS = golden_runs()
+PAIRS, IDS = golden_runs(include_big=True)      # cfg2 (K=3965) included: ~10 s of CPU with OpenMP
 
 
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)

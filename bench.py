@@ -108,6 +108,11 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     fv = decoder.FlashViterbi(local_rank)
     fv.set_model(A, B, Pi)
+    # The timed region runs the DENSE streaming kernel (every one of the K*K cells of every step is read
+    # and evaluated: that is what "K*K*T cells" counts).  The library's AUTO choice for this model is the
+    # sparse walk (non-zero transitions only, same bits out); it is measured afterwards and reported as
+    # `sparse_walk`, never as `value`.
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
     if dist is not None:
         # torch.distributed is the rendezvous only: the 128-byte RCCL id travels over it, the
         # data-path collective (one all-gather per decode) is issued by libflashvit on its own stream
@@ -125,6 +130,7 @@ def main():
                 fv.close()
             fv = decoder.FlashViterbi(local_rank)
             fv.set_model(A, B, Pi)
+            fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
             fv.set_partition(rank, world)
             gather_mode = "torch.distributed.all_gather + fv_merge_paths"
 
@@ -172,11 +178,38 @@ def main():
     achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
     ps_ = fv.decode_full(ob, N_SPLIT, decoder.MODE_SINGLE_PASS)
     ps = fv.stats()
+    # extra: the library's AUTO kernel for this model (sparse walk over the non-zero transitions)
+    sparse = None
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    for _ in range(2):
+        decode()
+    a_ = fv.stats()
+    if a_["kernel"] == decoder.KERNEL_SPARSE_Q16:
+        nd = max(3, args.steps // 4)
+        barrier()
+        t1 = time.perf_counter()
+        ssteps = 0.0
+        for _ in range(nd):
+            decode()
+            ssteps += fv.stats()["top_steps_ms"]
+        barrier()
+        sw = time.perf_counter() - t1
+        sparse = {"kernel": "fvk::trellis_step_sparse<1>", "transition_density": a_["density"],
+                  "decode_ms": 1e3 * sw / nd, "cells_per_sec_dense_equivalent": K * K * T * nd / sw,
+                  "launch_us": 1e3 * (ssteps / nd) / (T - 1), "stored_bytes_per_launch": a_["table_bytes_per_step"],
+                  "note": "only the non-zero transitions are stored and visited (log 0 = -inf can never win, "
+                          "reference FLASH_Viterbi_multithread.c:171): bit-identical output, fewer cells evaluated; "
+                          "not comparable with the HBM roofline of the K*K sweep"}
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
     traffic = None
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    kname = {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>",
+             3: "fvk::trellis_step<fvk::half_t,1,16,false>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>",
+             5: "fvk::trellis_step_sparse<1>"}[st["kernel"]]
     if os.path.isfile(tr_file):
         with open(tr_file) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            trj = json.load(f)
+        traffic = trj.get("by_kernel", {}).get(kname, {}).get("hbm_bytes_per_launch")
 
     if rank == 0:
         line = {
@@ -187,7 +220,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"FLASH Viterbi full-state decode K={K} T={T} M={M} prob={PROB} seed={SEED} "
                                    f"n_split={N_SPLIT} mode=reference (BASELINE configs[1])",
-                       "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine"}[st["kernel"]],
+                       "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16"}[st["kernel"]],
+                       "transition_density": st["density"],
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
                        "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none"},
             "decode_ms": 1e3 * dt / args.steps,
@@ -196,10 +230,12 @@ def main():
             "single_pass_mode_ms": ps["gpu_ms"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>", 3: "fvk::trellis_step<fvk::half_t,1,2,true>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>"}[st["kernel"]], "launch_us": launch_us,
+                         "kernel": kname, "launch_us": launch_us,
                          "alg_bytes_per_launch": alg_bytes_per_launch, "launches_per_decode": T - 1,
                          "table_bytes_streamed_per_launch": ps["table_bytes_per_step"]},
         }
+        if sparse is not None:
+            line["sparse_walk"] = sparse
         if args.gpus == 1 and not args.no_cpu_baseline:
             hip_sample, _, _ = fv.decode_full(ob[:CPU_SAMPLE_T], CPU_THREADS, decoder.MODE_REFERENCE)
             line["cpu_baseline"] = cpu_baseline(model64, ob, hip_sample.tolist())

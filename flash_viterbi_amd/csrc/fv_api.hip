@@ -55,6 +55,9 @@ struct fv_ctx {
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
     DevBuf<unsigned short> LA16, LAQ16;
+    DevBuf<uint4> SPdata;    // sparse CSC-Q16 table (fv_kernels.hip.inc, trellis_step_sparse)
+    DevBuf<int> SPoff, SPnwb;
+    double density = 1.0;    // finite fraction of log A
     float window16 = 0.0f;   // 2 * max |half(L) - L| over the finite table entries
     float windowq = 0.0f, qscale = -1.0f;   // same for the fixed-point table; value = code * qscale
     DevBuf<double> LA64, LB64T, LPi64;
@@ -101,7 +104,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t device_bytes(const fv_ctx *c)
 {
-    return c->LA32.bytes() + c->LA16.bytes() + c->LAQ16.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
+    return c->LA32.bytes() + c->LA16.bytes() + c->LAQ16.bytes() + c->SPdata.bytes() + c->SPoff.bytes() + c->SPnwb.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
@@ -134,8 +137,12 @@ int pick_kernel(const fv_ctx *ctx)
     // Measured at K=3965 (us per step of the whole-sequence pass): q16 9.5, f32 11.1, f16 12.8, f64 20.7.
     // binary16's 2^-11 relative spacing makes its window ~0.008 wide (~430 extra candidates and ~7 lane
     // rescans per step); 16-bit fixed point has a window of ~3e-4 (~21 and 0.4) at the same 2 B/cell.
-    if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_F32_REFINE) return ctx->opt_kernel;
-    return FV_KERNEL_Q16_REFINE;
+    if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_F32_REFINE ||
+        ctx->opt_kernel == FV_KERNEL_Q16_REFINE)
+        return ctx->opt_kernel;
+    if (ctx->opt_kernel == FV_KERNEL_SPARSE_Q16) return ctx->SPdata.p ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_Q16_REFINE;
+    // AUTO: the sparse walk visits only finite entries; it wins clearly below ~1/3 density
+    return (ctx->SPdata.p && ctx->density <= 0.35) ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_Q16_REFINE;
 }
 
 // Kernel variants: chunks of U 16-byte loads per lane, double-buffered in registers.
@@ -202,9 +209,36 @@ int launch_step(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     return launch_step_nb<TA, 8>(ctx, slots, nb, reverse);
 }
 
+template <int NB>
+int launch_sparse_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb)
+{
+    fvk::SparseArgs<NB> a;
+    a.data = ctx->SPdata.p; a.tile_off = ctx->SPoff.p; a.tile_nwb = ctx->SPnwb.p;
+    a.LA64 = ctx->LA64.p; a.counters = ctx->d_counters.p;
+    a.K = ctx->K; a.nrows = ctx->nrows;
+    a.ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    a.nb = nb; a.debug = ctx->opt_debug;
+    a.window = ctx->windowq; a.qscale = ctx->qscale;
+    for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
+    hipLaunchKernelGGL((fvk::trellis_step_sparse<NB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::SP_BLOCK),
+                       fvk::sparse_lds_bytes<NB>(ctx->nrows), ctx->stream, a);
+    FV_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_sparse(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb)
+{
+    if (nb <= 1) return launch_sparse_nb<1>(ctx, slots, nb);
+    if (nb <= 2) return launch_sparse_nb<2>(ctx, slots, nb);
+    if (nb <= 4) return launch_sparse_nb<4>(ctx, slots, nb);
+    return launch_sparse_nb<8>(ctx, slots, nb);
+}
+
 int launch_step_kernel(fv_ctx *ctx, int kernel, const fvk::TaskSlot *slots, int nb, int reverse)
 {
     switch (kernel) {
+    case FV_KERNEL_SPARSE_Q16: return launch_sparse(ctx, slots, nb);
     case FV_KERNEL_F64_STREAM: return launch_step<double>(ctx, slots, nb, reverse);
     case FV_KERNEL_F32_REFINE: return launch_step<float>(ctx, slots, nb, reverse);
     case FV_KERNEL_Q16_REFINE: return launch_step<fvk::q16_t>(ctx, slots, nb, reverse);
@@ -456,7 +490,9 @@ extern "C" int fv_create(fv_ctx **out, int device)
         (rc = allow_big_lds<fvk::half_t, 1>(ctx)) || (rc = allow_big_lds<fvk::half_t, 2>(ctx)) ||
         (rc = allow_big_lds<fvk::half_t, 4>(ctx)) || (rc = allow_big_lds<fvk::half_t, 8>(ctx)) ||
         (rc = allow_big_lds<fvk::q16_t, 1>(ctx)) || (rc = allow_big_lds<fvk::q16_t, 2>(ctx)) ||
-        (rc = allow_big_lds<fvk::q16_t, 4>(ctx)) || (rc = allow_big_lds<fvk::q16_t, 8>(ctx)))
+        (rc = allow_big_lds<fvk::q16_t, 4>(ctx)) || (rc = allow_big_lds<fvk::q16_t, 8>(ctx)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<1>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<2>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<4>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<8>)))
         return fail(rc);
     if ((rc = fvb::allow_big_lds(ctx->detail))) return fail(rc);
     *out = ctx;
@@ -469,7 +505,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
-    ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
+    ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release(); ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
@@ -575,6 +611,59 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     ctx->qscale = -stepf;
     FV_HIP(ctx->LAQ16.ensure(tab));
     FV_HIP(hipMemcpy(ctx->LAQ16.p, hq.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
+    // sparse form of the same codes (CSC-Q16, see trellis_step_sparse): per tile, per column, the finite
+    // entries in ascending k as (k << 16 | code), 4 per lane load, columns padded to the tile's longest
+    ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release();
+    ctx->density = 1.0;
+    if (K <= 65536) {
+        std::vector<int> off(ntiles), nwbv(ntiles);
+        std::vector<std::vector<uint32_t>> cols((size_t)ntiles * fvk::TILE_W);
+        parallel_rows(ntiles, [&](int a, int b) {
+            for (int tl = a; tl < b; ++tl)
+                for (int c = 0; c < fvk::TILE_W; ++c) {
+                    const int i = tl * fvk::TILE_W + c;
+                    if (i >= K) continue;
+                    std::vector<uint32_t> &v = cols[(size_t)tl * fvk::TILE_W + c];
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned short code = hq[fvk::tab_index<8>(k, i, nrows)];
+                        if (code != 0xFFFFu) v.push_back(((uint32_t)k << 16) | code);
+                    }
+                }
+        });
+        size_t nnz = 0, total = 0;
+        for (int tl = 0; tl < ntiles; ++tl) {
+            size_t longest = 0;
+            for (int c = 0; c < fvk::TILE_W; ++c) {
+                const size_t n = cols[(size_t)tl * fvk::TILE_W + c].size();
+                nnz += n; longest = std::max(longest, n);
+            }
+            const int nch = (int)((longest + 3) / 4);
+            nwbv[tl] = (nch + 3) / 4;
+            off[tl] = (int)total;
+            total += (size_t)nwbv[tl] * 4 * fvk::TILE_W;
+        }
+        ctx->density = (double)nnz / ((double)K * K);
+        if (total < (size_t)1 << 30 && total > 0) {
+            std::vector<uint4> sp(total);
+            const uint32_t pad = 0x0000FFFFu;           // k = 0, code = 0xffff (-inf)
+            parallel_rows(ntiles, [&](int a, int b) {
+                for (int tl = a; tl < b; ++tl)
+                    for (int j = 0; j < nwbv[tl] * 4; ++j)
+                        for (int c = 0; c < fvk::TILE_W; ++c) {
+                            const std::vector<uint32_t> &v = cols[(size_t)tl * fvk::TILE_W + c];
+                            uint32_t e[4];
+                            for (int q = 0; q < 4; ++q) e[q] = (size_t)(4 * j + q) < v.size() ? v[4 * j + q] : pad;
+                            sp[(size_t)off[tl] + (size_t)j * fvk::TILE_W + c] = make_uint4(e[0], e[1], e[2], e[3]);
+                        }
+            });
+            FV_HIP(ctx->SPdata.ensure(total));
+            FV_HIP(ctx->SPoff.ensure(ntiles));
+            FV_HIP(ctx->SPnwb.ensure(ntiles));
+            FV_HIP(hipMemcpy(ctx->SPdata.p, sp.data(), total * sizeof(uint4), hipMemcpyHostToDevice));
+            FV_HIP(hipMemcpy(ctx->SPoff.p, off.data(), ntiles * sizeof(int), hipMemcpyHostToDevice));
+            FV_HIP(hipMemcpy(ctx->SPnwb.p, nwbv.data(), ntiles * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     FV_HIP(ctx->LA64.ensure(tab));
     FV_HIP(ctx->LA32.ensure(tab));
     FV_HIP(ctx->LA16.ensure(tab));
@@ -601,7 +690,7 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
     if (!ctx) return FV_ERR_ARG;
     switch (key) {
     case FV_OPT_KERNEL:
-        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_Q16_REFINE) return FV_ERR_ARG;
+        if (value < FV_KERNEL_AUTO || value > FV_KERNEL_SPARSE_Q16) return FV_ERR_ARG;
         ctx->opt_kernel = (int)value; return FV_OK;
     case FV_OPT_MAX_BATCH:
         if (value < 1 || value > fvk::MAX_BATCH) return FV_ERR_ARG;
@@ -644,6 +733,8 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     ctx->stats.kernel = kernel;
     ctx->stats.generations = plan.generations();
     ctx->stats.table_bytes_per_step = (long long)((ctx->K + fvk::TILE_W - 1) / fvk::TILE_W) * ctx->nrows * fvk::TILE_W * (kernel == FV_KERNEL_F64_STREAM ? 8 : kernel == FV_KERNEL_F32_REFINE ? 4 : 2);
+    if (kernel == FV_KERNEL_SPARSE_Q16) ctx->stats.table_bytes_per_step = (long long)ctx->SPdata.bytes();
+    ctx->stats.density = ctx->density;
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));

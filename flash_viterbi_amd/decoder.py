@@ -13,7 +13,7 @@ from . import build as _build
 
 MODE_REFERENCE = 0
 MODE_SINGLE_PASS = 1
-KERNEL_AUTO, KERNEL_F64_STREAM, KERNEL_F32_REFINE, KERNEL_F16_REFINE, KERNEL_Q16_REFINE = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_F64_STREAM, KERNEL_F32_REFINE, KERNEL_F16_REFINE, KERNEL_Q16_REFINE, KERNEL_SPARSE_Q16 = 0, 1, 2, 3, 4, 5
 OPT_KERNEL, OPT_MAX_BATCH, OPT_PROFILE, OPT_DEBUG = 1, 2, 3, 100
 WARN_BEAM_MISS = 1
 UNIQUE_ID_BYTES = 128
@@ -28,7 +28,7 @@ class Stats(ctypes.Structure):
                 ("cells", ctypes.c_longlong), ("alg_bytes", ctypes.c_longlong),
                 ("table_bytes_per_step", ctypes.c_longlong), ("device_bytes", ctypes.c_longlong),
                 ("refine_near", ctypes.c_longlong), ("refine_rescan", ctypes.c_longlong),
-                ("beam_exact_sets", ctypes.c_longlong), ("beam_ties", ctypes.c_longlong),
+                ("beam_exact_sets", ctypes.c_longlong), ("beam_ties", ctypes.c_longlong), ("density", ctypes.c_double),
                 ("passes", ctypes.c_int), ("generations", ctypes.c_int), ("kernel", ctypes.c_int),
                 ("ranks", ctypes.c_int)]
 

@@ -12,7 +12,9 @@ from flash_viterbi_amd import decoder
 pytestmark = pytest.mark.gpu
 
 PAIRS, IDS = golden_runs(include_big=True, algo="flash")
-KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE, decoder.KERNEL_Q16_REFINE]
+KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE, decoder.KERNEL_Q16_REFINE,
+           decoder.KERNEL_SPARSE_Q16]
+KIDS = ["f64stream", "f32refine", "f16refine", "q16refine", "sparseq16"]
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +33,7 @@ def ctxs():
         fv.close()
 
 
-@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine", "f16refine", "q16refine"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KIDS)
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_reference_mode_matches_golden(ctxs, g, r, kernel):
     fv, ob = ctxs(g)
@@ -115,7 +117,7 @@ def test_argument_errors():
     fv.close()
 
 
-@pytest.mark.parametrize("kernel", KERNELS, ids=["f64stream", "f32refine", "f16refine", "q16refine"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KIDS)
 @pytest.mark.parametrize("bits", [2, 4, 8, 2 | 4 | 8], ids=["noreverse", "altloads", "fulllast", "all"])
 def test_tuning_switches_do_not_change_results(ctxs, kernel, bits):
     """Sweep direction, load schedule and the single-column last step are speed knobs only."""

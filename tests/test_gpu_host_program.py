@@ -1,0 +1,66 @@
+"""GPU: the C host programs end to end — generate_data text files in, the reference's three stdout
+lines out (`time:`, `path: [...]`, `memory:`), patched and compiled exactly the way run_hip.py (and the
+reference's run.py) does it.  Paths and memory figures must equal the reference binaries' goldens."""
+import importlib.util
+import os
+import re
+import subprocess
+
+import pytest
+
+import modelgen
+from conftest import ROOT, load_goldens
+from flash_viterbi_amd import build as fvbuild
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_hip_module():
+    spec = importlib.util.spec_from_file_location("run_hip", os.path.join(ROOT, "flash_viterbi_amd", "src", "run_hip.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("name,case,algo", [("FLASH_Viterbi_hip", "ds_K77_M7_T33", "flash"),
+                                            ("FLASH_BS_Viterbi_hip", "ds_K77_M7_T33", "flashbs"),
+                                            ("FLASH_Viterbi_hip", "cfg1_K128_T256", "flash"),
+                                            ("FLASH_BS_Viterbi_hip", "ties_semi_K96_T80", "flashbs")])
+def test_host_program_prints_reference_path(tmp_path, name, case, algo):
+    run_hip = _run_hip_module()
+    g = next(x for x in load_goldens() if x["name"] == case)
+    spec = g["spec"]
+    data_dir = str(tmp_path) + os.sep
+    modelgen.write_text(spec, data_dir)
+    src = open(os.path.join(ROOT, "flash_viterbi_amd", "src", name + ".c")).read()
+    for r in [x for x in g["runs"] if x["algo"] == algo][:2]:
+        p = {"K_STATE": spec["K"], "T_STATE": spec["M"], "obserRouteLEN": spec["T"], "prob": spec["prob"],
+             "MAX_THREADS": r["N"], "BeamSearchWidth": r.get("B", 32)}
+        run_hip.data_path = data_dir
+        text = run_hip.patch_config(src, name, p)
+        c = tmp_path / (name + "_modified.c")
+        c.write_text(text)
+        exe = str(tmp_path / (name + "_modified"))
+        res = subprocess.run(fvbuild.program_cc(str(c), exe), capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        for cache in ("0", "1", "1"):       # text parse, cache write, cache read
+            out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, FV_BIN_CACHE=cache))
+            assert out.returncode == 0, out.stderr
+            assert re.search(r"time: ([\d.]+)", out.stdout)                       # reference run.py:75
+            assert int(re.search(r"memory: (\d+)", out.stdout).group(1)) == r["memory"]   # run.py:76
+            path = [int(x) for x in re.search(r"path: \[([^\]]*)\]", out.stdout).group(1).split()]
+            assert path == r["path"]
+            assert float(re.search(r"score: (\S+)", out.stderr).group(1)) == pytest.approx(r["score"], rel=1e-7)
+
+
+def test_host_program_reports_missing_input(tmp_path):
+    run_hip = _run_hip_module()
+    src = open(os.path.join(ROOT, "flash_viterbi_amd", "src", "FLASH_Viterbi_hip.c")).read()
+    run_hip.data_path = str(tmp_path) + os.sep
+    p = {"K_STATE": 8, "T_STATE": 3, "obserRouteLEN": 5, "prob": 0.5, "MAX_THREADS": 1, "BeamSearchWidth": 4}
+    c = tmp_path / "x.c"
+    c.write_text(run_hip.patch_config(src, "FLASH_Viterbi_hip", p))
+    exe = str(tmp_path / "x")
+    assert subprocess.run(fvbuild.program_cc(str(c), exe), capture_output=True).returncode == 0
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "cannot open" in out.stderr

@@ -52,6 +52,7 @@ struct fv_ctx {
 
     // model
     int K = 0, M = 0, nrows = 0;
+    bool full_ok = false;    // the full-state kernels can take this K (one score row fits LDS)
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
     DevBuf<unsigned short> LA16, LAQ16;
@@ -71,6 +72,8 @@ struct fv_ctx {
     DevBuf<int> d_hstate, d_slot_state, d_flags;
     DevBuf<double> LA64R;                            // row-gather copy of the float64 table (built on first beam decode)
     DevBuf<int2> d_tie_list;
+    DevBuf<float> d_cut;         // [T][2] theta and duplicate flag of every step's heap
+    DevBuf<int> d_dupwin;        // [T]
     DevBuf<unsigned int> d_tie_count;
 
     // options
@@ -108,7 +111,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes();
+           c->LA64R.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -293,7 +296,7 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
         }
     }
     FV_HIP(ctx->d_score.ensure(4));
-    FV_HIP(ctx->d_counters.ensure(4));
+    FV_HIP(ctx->d_counters.ensure(8));
     if (ctx->comm) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
     return 0;
 }
@@ -434,7 +437,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
         FV_HIP(hipMemcpyAsync(path_out, ctx->d_ans.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     float score = 0.f;
-    unsigned long long counters[4] = { 0, 0, 0, 0 };
+    unsigned long long counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     FV_HIP(hipMemcpyAsync(&score, ctx->d_score.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipMemcpyAsync(counters, ctx->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipStreamSynchronize(ctx->stream));
@@ -455,6 +458,8 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.refine_near = (long long)counters[0];
     st.refine_rescan = (long long)counters[1];
     st.beam_exact_sets = (long long)counters[2];
+    st.beam_dup_cols = (long long)counters[3];
+    st.beam_dup_steps = (long long)counters[4];
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
     bool neg = false;
@@ -509,7 +514,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release();
+    ctx->LA64R.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -527,13 +532,18 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipSetDevice(ctx->device));
     const int nrows = round_up(K, fvk::ROW_ALIGN);
     const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
-    if (fvk::step_lds_bytes<1>(nrows) > 160 * 1024) return FV_ERR_UNSUPPORTED;   // one score row must fit LDS
+    // the full-state step kernels keep one score row in LDS: beyond that K only the beam path is available
+    // (it needs the float64 table alone, which also keeps the host footprint at 8 B per entry)
+    const bool full_ok = fvk::step_lds_bytes<1>(nrows) <= 160 * 1024;
 
     const size_t tab = (size_t)ntiles * nrows * fvk::TILE_W;
     std::vector<double> h64;
     std::vector<float> h32;
     std::vector<unsigned short> h16;
-    try { h64.assign(tab, -HUGE_VAL); h32.assign(tab, -HUGE_VALF); h16.assign(tab, 0xFC00u /* -inf */); } catch (...) { return FV_ERR_NOMEM; }
+    try {
+        h64.assign(tab, -HUGE_VAL);
+        if (full_ok) { h32.assign(tab, -HUGE_VALF); h16.assign(tab, 0xFC00u /* -inf */); }
+    } catch (...) { return FV_ERR_NOMEM; }
     std::vector<double> dmax_row(K, 0.0);
     bool ok_range = true;
     std::vector<char> bad(K, 0), big(K, 0);
@@ -546,7 +556,9 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
                 if (x > 1.0f) big[k] = 1;
                 const double l = std::log((double)x);
                 const size_t e = fvk::tab_index<4>(k, i, nrows);
-                h64[e] = l; h32[e] = (float)l;
+                h64[e] = l;
+                if (!full_ok) continue;
+                h32[e] = (float)l;
                 const _Float16 hl = (_Float16)l;          // round to nearest even; -inf stays -inf
                 unsigned short hb;
                 std::memcpy(&hb, &hl, 2);
@@ -585,7 +597,10 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     // fixed-point table: step = (largest finite |log A|) / 65534, code = round(-L/step), 0xffff = -inf.
     // The kernel evaluates fma(code, -step, s) with step as a float, so the error is measured against
     // exactly that product (code * (double)(float)step is exact in double).
+    ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release();
+    ctx->density = 1.0;
     std::vector<unsigned short> hq;
+    if (full_ok) {
     try { hq.assign(tab, 0xFFFFu); } catch (...) { return FV_ERR_NOMEM; }
     double lmax = 0.0;
     for (size_t e = 0; e < tab; ++e) if (std::isfinite(h64[e])) lmax = std::max(lmax, -h64[e]);
@@ -613,8 +628,6 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LAQ16.p, hq.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
     // sparse form of the same codes (CSC-Q16, see trellis_step_sparse): per tile, per column, the finite
     // entries in ascending k as (k << 16 | code), 4 per lane load, columns padded to the tile's longest
-    ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release();
-    ctx->density = 1.0;
     if (K <= 65536) {
         std::vector<int> off(ntiles), nwbv(ntiles);
         std::vector<std::vector<uint32_t>> cols((size_t)ntiles * fvk::TILE_W);
@@ -664,19 +677,24 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
             FV_HIP(hipMemcpy(ctx->SPnwb.p, nwbv.data(), ntiles * sizeof(int), hipMemcpyHostToDevice));
         }
     }
+    }   // full_ok
     FV_HIP(ctx->LA64.ensure(tab));
-    FV_HIP(ctx->LA32.ensure(tab));
-    FV_HIP(ctx->LA16.ensure(tab));
-    FV_HIP(hipMemcpy(ctx->LA16.p, h16.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
+    if (full_ok) {
+        FV_HIP(ctx->LA32.ensure(tab));
+        FV_HIP(ctx->LA16.ensure(tab));
+        FV_HIP(hipMemcpy(ctx->LA16.p, h16.data(), tab * sizeof(unsigned short), hipMemcpyHostToDevice));
+        FV_HIP(hipMemcpy(ctx->LA32.p, h32.data(), tab * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release();
+    }
     FV_HIP(ctx->LB64T.ensure((size_t)M * K));
     FV_HIP(ctx->LB32T.ensure((size_t)M * K));
     FV_HIP(ctx->LPi64.ensure(K));
     FV_HIP(hipMemcpy(ctx->LA64.p, h64.data(), tab * sizeof(double), hipMemcpyHostToDevice));
-    FV_HIP(hipMemcpy(ctx->LA32.p, h32.data(), tab * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LB64T.p, b64.data(), b64.size() * sizeof(double), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->K = K; ctx->M = M; ctx->nrows = nrows;
+    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok;
     ctx->LA64R.release();                 // rebuilt from the new table on the next beam decode
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
@@ -707,6 +725,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
 {
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
+    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~38000)"; return FV_ERR_UNSUPPORTED; }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     if (ctx->opt_kernel >= FV_KERNEL_F32_REFINE && !ctx->logs_nonpositive) {
         ctx->detail = "the filter+refine kernels need every model entry in [0,1]";
@@ -738,7 +757,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     size_t nprof = 0;
@@ -775,7 +794,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.n = std::min(fvb::BEAM_CHUNK, count - base);
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
-                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j) };
+                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), ctx->d_cut.p + (size_t)j * 2 };
             }
             hipLaunchKernelGGL(fvb::topb_select, dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
             FV_HIP(hipGetLastError());
@@ -805,6 +824,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             fvb::BeamStepArgs a;
             a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
             a.tie_cap = (unsigned int)ctx->d_tie_list.n;
+            a.counters = ctx->d_counters.p;
             a.K = K; a.nrows = ctx->nrows; a.beam = beam; a.ntiles = ntiles;
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
@@ -815,6 +835,8 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
                 a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
                 a.p[q].j = j;
+                a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * 2;
+                a.p[q].dupwin = ctx->d_dupwin.p + j;
             }
             hipLaunchKernelGGL(fvb::beam_step, dim3(ntiles, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
                                ctx->stream, a);
@@ -888,6 +910,9 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     FV_HIP(ctx->d_slot_state.ensure((size_t)T * beam_width));
     FV_HIP(ctx->d_tie_list.ensure((size_t)T * ctx->K));
     FV_HIP(ctx->d_tie_count.ensure(4));
+    FV_HIP(ctx->d_cut.ensure((size_t)T * 2));
+    FV_HIP(ctx->d_dupwin.ensure(T));
+    FV_HIP(hipMemsetAsync(ctx->d_dupwin.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (!ctx->LA64R.p) {
         const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
         FV_HIP(ctx->LA64R.ensure((size_t)ntiles * ctx->nrows * fvk::TILE_W));
@@ -904,7 +929,7 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));

@@ -28,7 +28,8 @@ class Stats(ctypes.Structure):
                 ("cells", ctypes.c_longlong), ("alg_bytes", ctypes.c_longlong),
                 ("table_bytes_per_step", ctypes.c_longlong), ("device_bytes", ctypes.c_longlong),
                 ("refine_near", ctypes.c_longlong), ("refine_rescan", ctypes.c_longlong),
-                ("beam_exact_sets", ctypes.c_longlong), ("beam_ties", ctypes.c_longlong), ("density", ctypes.c_double),
+                ("beam_exact_sets", ctypes.c_longlong), ("beam_ties", ctypes.c_longlong),
+                ("beam_dup_cols", ctypes.c_longlong), ("beam_dup_steps", ctypes.c_longlong), ("density", ctypes.c_double),
                 ("passes", ctypes.c_int), ("generations", ctypes.c_int), ("kernel", ctypes.c_int),
                 ("ranks", ctypes.c_int)]
 

@@ -44,7 +44,9 @@ enum {
     FV_MODE_REFERENCE = 0,
     /* One forward pass over [0,T-1] with full back-pointers + one backtrack.  Equal to the
      * reference in exact arithmetic; float rounding histories of right-hand sub-tasks differ,
-     * so equality with the reference binary is empirical (it held on every fixture). */
+     * so equality with the reference binary is empirical (it held on every fixture).
+     * fv_decode_beam: ordinary one-pass beam search — NOT the reference's result, whose right-hand
+     * tasks re-run the beam conditioned on Ans[mid] and can leave the first pass's beam. */
     FV_MODE_SINGLE_PASS = 1,
 };
 
@@ -89,6 +91,8 @@ typedef struct {
     long long refine_rescan;  /* filter kernels: lanes that had to rescan their rows */
     long long beam_exact_sets;/* FLASH-BS: steps whose heap members needed the exact replay (duplicate scores at the cut) */
     long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order */
+    long long beam_dup_cols;  /* FLASH-BS statistics: columns won by an entry whose value equals a duplicated cut value */
+    long long beam_dup_steps; /* ... and the number of steps in which that happened at least once */
     double density;           /* non-zero fraction of the transition matrix */
     int passes;               /* forward passes run (reference mode: one per right-hand task) */
     int generations;          /* dependent batches of passes */

@@ -22,7 +22,9 @@ print(f"{kind} K={K} T={T} N={N} B={B}: gpu_ms {best['gpu_ms']:.3f} decode_ms {b
       f"near {best['refine_near']} rescan {best['refine_rescan']} exact_sets {best['beam_exact_sets']} rc {rc}", flush=True)
 if "--no-oracle" not in sys.argv:
     oracle.set_threads(16)
+    print("oracle: building log tables ...", flush=True)
     om = oracle.OracleModel(A, Bm, Pi)
+    print("oracle: decoding ...", flush=True)
     t0 = time.time()
     op, osc, oc, orc = om.full_decode(ob, N) if kind == "full" else om.beam_decode(ob, N, B)
     dt = time.time() - t0

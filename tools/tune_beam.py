@@ -28,4 +28,4 @@ for B, ref in cases:
     steps = best["task_steps"]
     print(f"K {K} B {B} T {T}: gpu_ms {best['gpu_ms']:.3f} top_ms {best['top_pass_ms']:.3f} us/step(top) {1e3*best['top_pass_ms']/(T-1):.1f} "
           f"launches {best['step_launches']} task_steps {steps} cells/s {K*B*T/(best['gpu_ms']*1e-3):.3e} "
-          f"roofline(4*B*K*(T-1)/top) {4.0*B*K*(T-1)/(best['top_pass_ms']*1e-3)/8e12:.4f} exact_sets {best['beam_exact_sets']} ok {ok} rc {rc}", flush=True)
+          f"roofline(4*B*K*(T-1)/top) {4.0*B*K*(T-1)/(best['top_pass_ms']*1e-3)/8e12:.4f} exact_sets {best['beam_exact_sets']} dup_steps {best['beam_dup_steps']} dup_cols {best['beam_dup_cols']} ok {ok} rc {rc}", flush=True)

@@ -1,0 +1,103 @@
+"""GPU: size-independent properties at BASELINE's full sizes (too large for the oracle in a test run).
+
+cfg3 size (K=3965, T=4096, N=8): the decoded path is a valid state sequence (every transition and
+emission has non-zero probability), its log-score re-computed on the host in float64 equals the
+returned score to 1e-5 relative, and every kernel / schedule agrees with every other bit for bit."""
+import numpy as np
+import pytest
+
+import modelgen
+from flash_viterbi_amd import decoder
+
+pytestmark = pytest.mark.gpu
+
+
+def path_logscore64(A, B, Pi, ob, path):
+    p = np.asarray(path, dtype=np.int64)
+    with np.errstate(divide="ignore"):
+        s = np.log(np.float64(Pi[p[0]])) + np.log(np.float64(B[p[0], ob[0]]))
+        s += np.log(A[p[:-1], p[1:]].astype(np.float64)).sum()
+        s += np.log(B[p[1:], ob[1:]].astype(np.float64)).sum()
+    return float(s)
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    spec = dict(kind="data_script", K=3965, M=50, T=4096, prob=0.112, seed=12)
+    A, B, Pi, ob = modelgen.model32(spec)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    yield A, B, Pi, ob, fv
+    fv.close()
+
+
+def test_cfg3_path_is_valid_and_score_consistent(cfg3):
+    A, B, Pi, ob, fv = cfg3
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    path, score, rc = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
+    assert rc == 0 and path.min() >= 0 and path.max() < 3965
+    s64 = path_logscore64(A, B, Pi, ob, path)
+    assert np.isfinite(s64), "decoded path uses a zero-probability transition or emission"
+    assert abs(s64 - float(score)) <= 1e-5 * abs(s64)          # north_star tolerance for log-scores
+    st = fv.stats()
+    assert st["passes"] == 2047 and st["kernel"] == decoder.KERNEL_SPARSE_Q16
+
+
+def test_cfg3_all_kernels_and_schedules_agree(cfg3):
+    A, B, Pi, ob, fv = cfg3
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    ref_path, ref_score, _ = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
+    for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F64_STREAM):
+        fv.set_option(decoder.OPT_KERNEL, kernel)
+        path, score, rc = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
+        assert rc == 0 and (path == ref_path).all() and score == ref_score, kernel
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    # other segmentations replay different passes but must land on the same optimum here
+    for n in (1, 16):
+        path, score, rc = fv.decode_full(ob, n, decoder.MODE_REFERENCE)
+        assert rc == 0 and score == ref_score
+        assert abs(path_logscore64(A, B, Pi, ob, path) - float(score)) <= 1e-5 * abs(float(score))
+    sp_path, sp_score, _ = fv.decode_full(ob, 8, decoder.MODE_SINGLE_PASS)
+    assert sp_score == ref_score and abs(path_logscore64(A, B, Pi, ob, sp_path) - float(sp_score)) <= 1e-5 * abs(float(sp_score))
+    v_path, v_score, _ = fv.decode_vanilla(ob)
+    assert abs(float(v_score) - float(ref_score)) <= 1e-5 * abs(float(ref_score))
+
+
+def test_cfg3_beam_path_valid_and_not_better_than_full(cfg3):
+    A, B, Pi, ob, fv = cfg3
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+    _, full_score, _ = fv.decode_full(ob[:512], 8, decoder.MODE_REFERENCE)
+    for beam in (64, 512):
+        path, score, rc = fv.decode_beam(ob[:512], 8, beam, decoder.MODE_REFERENCE)
+        assert rc in (0, decoder.WARN_BEAM_MISS)
+        assert (rc == decoder.WARN_BEAM_MISS) == bool((path < 0).any())     # the reference prints -1 after a miss
+        assert path.max() < 3965
+        if rc == 0:
+            s64 = path_logscore64(A, B, Pi, ob[:512], path)
+            assert np.isfinite(s64)
+            assert s64 <= float(full_score) + 1e-5 * abs(float(full_score))   # a pruned search cannot beat the optimum
+
+
+@pytest.mark.parametrize("prob,expect", [(0.9, decoder.KERNEL_Q16_REFINE), (0.5, decoder.KERNEL_Q16_REFINE),
+                                         (0.3, decoder.KERNEL_SPARSE_Q16)])
+def test_auto_kernel_choice_by_density_and_parity(prob, expect):
+    """Dense models take the dense 16-bit table, sparse ones the walk; both equal the oracle."""
+    import oracle
+    spec = dict(kind="data_script", K=600, M=12, T=80, prob=prob, seed=41)
+    A, B, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, B, Pi)
+    opath, oscore, _, _ = om.full_decode(ob, 4)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    path, score, rc = fv.decode_full(ob, 4)
+    st = fv.stats()
+    assert st["kernel"] == expect and abs(st["density"] - prob) < 0.03
+    assert rc == 0 and path.tolist() == opath.tolist() and score == oscore
+    for kernel in (decoder.KERNEL_SPARSE_Q16, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F16_REFINE):
+        fv.set_option(decoder.OPT_KERNEL, kernel)
+        path, score, rc = fv.decode_full(ob, 4)
+        assert path.tolist() == opath.tolist() and score == oscore
+    bo, bs, _, brc = om.beam_decode(ob, 4, 40)
+    bp, bsc, rc = fv.decode_beam(ob, 4, 40)
+    assert bp.tolist() == bo.tolist() and bsc == bs and rc == brc
+    fv.close()

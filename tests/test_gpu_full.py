@@ -182,3 +182,27 @@ def test_partitioned_decode_merges_to_single_rank_result(ctxs, nranks):
     T = len(ob)
     assert decoder.merge_paths(T, 8, nranks, np.stack(parts_full)).tolist() == want_full
     assert decoder.merge_paths(T, 8, nranks, np.stack(parts_beam)).tolist() == want_beam
+
+
+@pytest.mark.parametrize("K,M,T,N", [(1, 2, 5, 1), (2, 2, 9, 1), (3, 3, 17, 4), (17, 2, 300, 16), (33, 50, 2, 1)])
+def test_tiny_and_odd_sizes_match_oracle(K, M, T, N):
+    import modelgen
+    spec = dict(kind="data_script", K=K, M=M, T=T, prob=1.0 if K < 4 else 0.6, seed=7 + K)
+    A, B, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, B, Pi)
+    opath, oscore, _, _ = om.full_decode(ob, N)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    for kernel in KERNELS:
+        fv.set_option(decoder.OPT_KERNEL, kernel)
+        path, score, rc = fv.decode_full(ob, N)
+        assert rc == 0 and path.tolist() == opath.tolist() and score == oscore, kernel
+    vp, vs, _ = om.vanilla_decode(ob)
+    gp, gs, _ = fv.decode_vanilla(ob)
+    assert gp.tolist() == vp.tolist() and gs == vs
+    if K >= 2:
+        for beam in sorted({2, K}):
+            bo, bs, _, brc = om.beam_decode(ob, N, beam)
+            bp, bsc, rc = fv.decode_beam(ob, N, beam)
+            assert bp.tolist() == bo.tolist() and bsc == bs and rc == brc
+    fv.close()

@@ -221,6 +221,8 @@ def main():
             "config": {"workload": f"FLASH Viterbi full-state decode K={K} T={T} M={M} prob={PROB} seed={SEED} "
                                    f"n_split={N_SPLIT} mode=reference (BASELINE configs[1])",
                        "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16"}[st["kernel"]],
+                       "kernel_note": "dense K*K sweep forced for value/roofline; the library's AUTO choice for this "
+                                      "model is the sparse walk, reported separately as sparse_walk",
                        "transition_density": st["density"],
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
                        "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none"},

@@ -84,6 +84,7 @@ struct fv_ctx {
     int opt_debug = 0;       // FV_OPT_DEBUG bits: 1 skip refine (timing only), 2 no reverse sweep, 4 alternate unroll
     std::vector<hipEvent_t> prof_events;
     std::vector<int> h_ob;
+    std::vector<hipGraphExec_t> graphs;     // experiment (FV_OPT_DEBUG bit 6): destroyed after the decode's sync
 
     // comm
     ncclComm_t comm = nullptr;
@@ -340,7 +341,10 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows)));
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
     const bool col_last = !(ctx->opt_debug & 8);  // FV_OPT_DEBUG bit 3: run every last step as a full step
-    if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
+    // FV_OPT_DEBUG bit 6 (experiment): capture this generation's step launches into a hipGraph and replay it
+    const bool use_graph = (ctx->opt_debug & 64) && !ctx->opt_profile;
+    if (use_graph) FV_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    if (whole_gen && !use_graph) FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     // passes are sorted longest first: at lock-step s the passes with len >= s are a prefix; those with
     // len == s are finishing and (unless they are the whole-sequence pass) only need one column
     int active = np;
@@ -386,6 +390,16 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
             FV_HIP(hipGetLastError());
             ctx->stats.column_steps += c.n;
         }
+    }
+    if (use_graph) {
+        hipGraph_t g = nullptr;
+        FV_HIP(hipStreamEndCapture(ctx->stream, &g));
+        hipGraphExec_t ge = nullptr;
+        FV_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
+        FV_HIP(hipGraphLaunch(ge, ctx->stream));
+        ctx->graphs.push_back(ge);
+        (void)hipGraphDestroy(g);
     }
     if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream));
     // end states + chains
@@ -441,6 +455,8 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     FV_HIP(hipMemcpyAsync(&score, ctx->d_score.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipMemcpyAsync(counters, ctx->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipStreamSynchronize(ctx->stream));
+    for (hipGraphExec_t ge : ctx->graphs) (void)hipGraphExecDestroy(ge);
+    ctx->graphs.clear();
     if (!host.empty()) merge_gathered(plan, host, T, ctx->nranks, path_out);
     if (score_out) *score_out = score;
 

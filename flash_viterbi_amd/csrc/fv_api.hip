@@ -863,10 +863,10 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
         if ((rc = select(active, s))) return rc;
     }
     // off the critical path: exact layouts of every step's heap, tie fix-up, pass ends
-    for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
+    for (int base = 0; base < np; base += fvb::HEAP_CHUNK) {
         fvb::HeapAllArgs h;
         h.scores_all = ctx->d_scores.p; h.slot_val = ctx->d_slot_val.p; h.slot_state = ctx->d_slot_state.p;
-        h.K = K; h.beam = beam; h.n = std::min(fvb::BEAM_CHUNK, np - base);
+        h.K = K; h.beam = beam; h.n = std::min(fvb::HEAP_CHUNK, np - base);
         int longest = 0;
         for (int q = 0; q < h.n; ++q) {
             h.p[q] = fvb::HeapRange{ passes[base + q].L, passes[base + q].R };

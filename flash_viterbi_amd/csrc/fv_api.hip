@@ -476,6 +476,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.beam_exact_sets = (long long)counters[2];
     st.beam_dup_cols = (long long)counters[3];
     st.beam_dup_steps = (long long)counters[4];
+    if (counters[5]) { ctx->detail = "heap replay: producer/consumer hand-shake timed out"; return FV_ERR_DEVICE; }
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
     bool neg = false;
@@ -812,7 +813,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 const int j = passes[base + q].L + s;
                 a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), ctx->d_cut.p + (size_t)j * 2 };
             }
-            hipLaunchKernelGGL(fvb::topb_select, dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
+            hipLaunchKernelGGL(fvb::sel_kernel_for(K), dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
             FV_HIP(hipGetLastError());
         }
         return 0;
@@ -866,13 +867,14 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
     for (int base = 0; base < np; base += fvb::HEAP_CHUNK) {
         fvb::HeapAllArgs h;
         h.scores_all = ctx->d_scores.p; h.slot_val = ctx->d_slot_val.p; h.slot_state = ctx->d_slot_state.p;
+        h.err_counter = ctx->d_counters.p + 5;
         h.K = K; h.beam = beam; h.n = std::min(fvb::HEAP_CHUNK, np - base);
         int longest = 0;
         for (int q = 0; q < h.n; ++q) {
             h.p[q] = fvb::HeapRange{ passes[base + q].L, passes[base + q].R };
             longest = std::max(longest, passes[base + q].R - passes[base + q].L + 1);
         }
-        hipLaunchKernelGGL(fvb::heap_build_all, dim3(longest, h.n), dim3(64), fvb::heap_lds(beam), ctx->stream, h);
+        hipLaunchKernelGGL(fvb::heap_build_all, dim3(longest, h.n), dim3(128), fvb::heap_lds(beam), ctx->stream, h);
         FV_HIP(hipGetLastError());
     }
     {
@@ -906,6 +908,7 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     // beam > K reads uninitialised heap slots in the reference
     if (beam_width < 2 || beam_width > ctx->K) return FV_ERR_ARG;
     if (fvb::beam_step_lds(beam_width) > 150 * 1024 || fvb::heap_lds(beam_width) > 150 * 1024) return FV_ERR_UNSUPPORTED;
+    if (ctx->K > fvb::SEL_MAX_ROUNDS * fvb::SEL_BLOCK) return FV_ERR_UNSUPPORTED;      // topb_select: one bit per round
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     auto t0 = clk::now();
     FV_HIP(hipSetDevice(ctx->device));

@@ -790,6 +790,9 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
 
 namespace {
 
+// row pitch of the row-major float64 table the beam kernels gather from
+inline int beam_ld(int K) { return (K + fvb::BEAM_COLS - 1) / fvb::BEAM_COLS * fvb::BEAM_COLS; }
+
 // One generation of beam passes in lock-step (same shape as run_generation_full).  Buffers are indexed
 // by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
 // scores after consuming ob[j] (j = L: the init row), set_*[j] = the members of the heap built from
@@ -800,7 +803,6 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
     if (np == 0) return 0;
     std::stable_sort(passes.begin(), passes.end(),
                      [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
-    const int ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W;
     auto scores_at = [&](int j) { return ctx->d_scores.p + (size_t)j * K; };
     auto setv_at = [&](int j) { return ctx->d_hval.p + (size_t)j * beam; };
     auto sets_at = [&](int j) { return ctx->d_hstate.p + (size_t)j * beam; };
@@ -842,7 +844,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
             a.tie_cap = (unsigned int)ctx->d_tie_list.n;
             a.counters = ctx->d_counters.p;
-            a.K = K; a.nrows = ctx->nrows; a.beam = beam; a.ntiles = ntiles;
+            a.K = K; a.ld = beam_ld(K); a.beam = beam;
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
@@ -855,7 +857,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * 2;
                 a.p[q].dupwin = ctx->d_dupwin.p + j;
             }
-            hipLaunchKernelGGL(fvb::beam_step, dim3(ntiles, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
+            hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
                                ctx->stream, a);
             FV_HIP(hipGetLastError());
             ctx->stats.step_launches += 1;
@@ -882,7 +884,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
         f.LA64R = ctx->LA64R.p; f.LB32T = ctx->LB32T.p; f.ob = ctx->d_ob.p;
         f.tie_count = ctx->d_tie_count.p; f.tie_list = ctx->d_tie_list.p; f.tie_cap = (unsigned int)ctx->d_tie_list.n;
         f.slot_val = ctx->d_slot_val.p; f.slot_state = ctx->d_slot_state.p; f.bp = ctx->d_bp.p;
-        f.K = K; f.nrows = ctx->nrows; f.beam = beam;
+        f.K = K; f.ld = beam_ld(K); f.beam = beam;
         hipLaunchKernelGGL(fvb::tie_fixup, dim3(512), dim3(256), 0, ctx->stream, f);
         FV_HIP(hipGetLastError());
     }
@@ -933,9 +935,9 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     FV_HIP(ctx->d_dupwin.ensure(T));
     FV_HIP(hipMemsetAsync(ctx->d_dupwin.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (!ctx->LA64R.p) {
-        const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
-        FV_HIP(ctx->LA64R.ensure((size_t)ntiles * ctx->nrows * fvk::TILE_W));
-        hipLaunchKernelGGL(fvb::relayout_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LA64R.p, ctx->nrows, ntiles);
+        const int ld = beam_ld(ctx->K);
+        FV_HIP(ctx->LA64R.ensure((size_t)ctx->K * ld));
+        hipLaunchKernelGGL(fvb::relayout_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LA64R.p, ctx->K, ctx->nrows, ld);
         FV_HIP(hipGetLastError());
     }
 

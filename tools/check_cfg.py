@@ -11,13 +11,14 @@ B = int(sys.argv[5]) if kind == "beam" else 0
 spec = dict(kind="data_script", K=K, M=50, T=T, prob=0.112, seed=12)
 t0 = time.time(); A, Bm, Pi, ob = modelgen.model32(spec); print(f"model {time.time()-t0:.1f}s", flush=True)
 fv = decoder.FlashViterbi(0); t0 = time.time(); fv.set_model(A, Bm, Pi); print(f"set_model {time.time()-t0:.2f}s", flush=True)
+if os.environ.get("FV_KERNEL"): fv.set_option(decoder.OPT_KERNEL, int(os.environ["FV_KERNEL"]))   # 4 = dense Q16, 5 = sparse walk
 best = None
 for rep in range(3):
     p, s, rc = fv.decode_full(ob, N, 0) if kind == "full" else fv.decode_beam(ob, N, B, 0)
     st = fv.stats()
     if best is None or st["gpu_ms"] < best["gpu_ms"]: best = st
 cells = K * (B or K) * T
-print(f"{kind} K={K} T={T} N={N} B={B}: gpu_ms {best['gpu_ms']:.3f} decode_ms {best['decode_ms']:.3f} top_ms {best['top_pass_ms']:.3f} "
+print(f"{kind} K={K} T={T} N={N} B={B} kernel={best['kernel']}: gpu_ms {best['gpu_ms']:.3f} decode_ms {best['decode_ms']:.3f} top_ms {best['top_pass_ms']:.3f} "
       f"cells/s {cells/(best['gpu_ms']*1e-3):.4e} passes {best['passes']} launches {best['step_launches']} task_steps {best['task_steps']} "
       f"near {best['refine_near']} rescan {best['refine_rescan']} exact_sets {best['beam_exact_sets']} rc {rc}", flush=True)
 if "--no-oracle" not in sys.argv:

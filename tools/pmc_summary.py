@@ -1,0 +1,34 @@
+"""Builds profiles/r01_pmc_summary.csv and profiles/traffic.json from the three rocprofv3 --pmc passes that
+tools/prof_bench.sh leaves under gpurun_out/pmc{1,2,3}/ (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum + TCC_MISS_sum).
+Runs anywhere (no GPU)."""
+import csv, glob, json, os, re, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rows = {}
+for d in ("pmc1", "pmc2", "pmc3"):
+    for path in glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                rows.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+if not rows:
+    sys.exit("no counter_collection.csv under gpurun_out/pmc*/")
+out = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+with open(out, "w") as f:
+    f.write("kernel,counter,dispatches,mean,median,min,max\n")
+    for (k, c), v in sorted(rows.items()):
+        if k.startswith("__amd") or not ("fvk::" in k or "fvb::" in k):
+            continue
+        f.write(f"\"{k}\",{c},{len(v)},{statistics.mean(v):.3f},{statistics.median(v):.3f},{min(v):.3f},{max(v):.3f}\n")
+norm = lambda k: re.sub(r"^void ", "", re.sub(r"\(.*$", "", k)).replace(", ", ",")
+by = {}
+for want in ("fvk::trellis_step<fvk::q16_t,1,16,false>", "fvk::trellis_step_sparse<1>"):
+    m = {c: statistics.mean(v) for (k, c), v in rows.items() if norm(k) == want}
+    if {"FETCH_SIZE", "WRITE_SIZE", "TCC_MISS_sum", "TCC_HIT_sum"} <= set(m):
+        by[want] = {"FETCH_SIZE_KB_raw": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
+                    "TCC_MISS_sum": m["TCC_MISS_sum"], "TCC_HIT_sum": m["TCC_HIT_sum"],
+                    "hbm_bytes_per_launch": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
+                    "tcc_miss_bytes_per_launch": int(m["TCC_MISS_sum"] * 128)}
+tj = os.path.join(ROOT, "profiles", "traffic.json")
+old = json.load(open(tj))
+old["by_kernel"] = by
+json.dump(old, open(tj, "w"), indent=1)
+print(json.dumps(by, indent=1))

@@ -43,7 +43,9 @@ def test_beam_reference_mode_matches_golden(ctxs, g, r):
 
 @pytest.mark.parametrize("K,M,T,N,B,seed,prob", [(300, 11, 70, 4, 20, 201, 0.15), (1000, 50, 40, 3, 128, 202, 0.1),
                                                  (65, 5, 129, 8, 65, 203, 0.3), (2049, 20, 24, 1, 500, 204, 0.05),
-                                                 (130, 4, 90, 16, 2, 205, 0.5), (700, 9, 33, 5, 699, 206, 0.2)])
+                                                 (130, 4, 90, 16, 2, 205, 0.5), (700, 9, 33, 5, 699, 206, 0.2),
+                                                 # K > 4096 and K > 16384: the 16- and 64-round instantiations of topb_select
+                                                 (5000, 20, 20, 3, 100, 207, 0.05), (16500, 10, 10, 1, 300, 208, 0.02)])
 def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
     import modelgen
     spec = dict(kind="data_script", K=K, M=M, T=T, prob=prob, seed=seed)

@@ -65,7 +65,7 @@ struct fv_ctx {
 
     // workspace
     DevBuf<int> d_ob, d_ans, d_bp, d_gather;
-    DevBuf<float> d_rows, d_score;
+    DevBuf<float> d_rows, d_score, d_ckpt;            // d_ckpt: kept score rows of fv_decode_checkpoint
     DevBuf<unsigned long long> d_counters;
     // beam workspace
     DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
@@ -109,7 +109,7 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 size_t device_bytes(const fv_ctx *c)
 {
     return c->LA32.bytes() + c->LA16.bytes() + c->LAQ16.bytes() + c->SPdata.bytes() + c->SPoff.bytes() + c->SPnwb.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
-           c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() +
+           c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
            c->LA64R.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes();
@@ -528,7 +528,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release(); ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
-    ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release();
+    ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
     ctx->LA64R.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release();
@@ -974,6 +974,123 @@ extern "C" int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_ou
     ctx->vanilla = 0;
     ctx->opt_kernel = keep_kernel;
     return rc;
+}
+
+// checkpoint Viterbi.c:176-251 on the device.  First pass: T-1 steps of the baseline's recurrence with the
+// score row of every step that is a multiple of `step` written straight into its checkpoint slot (the next
+// step reads it from there; the arg rows of this pass are scratch).  Second pass: every segment
+// [c, next checkpoint] restarts from its kept row and re-runs its steps, this time keeping the arg rows;
+// the segments are independent, so they advance in lock-step and share table sweeps (up to 8 per launch)
+// instead of running last-to-first as the CPU program does.  End state and back-track as in vanilla.
+extern "C" int fv_decode_checkpoint(fv_ctx *ctx, const int *ob, int T, int step, int *path_out, float *score_out)
+{
+    if (!ctx || !ob || !path_out || T < 2) return FV_ERR_ARG;
+    if (ctx->K == 0) return FV_ERR_STATE;
+    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~38000)"; return FV_ERR_UNSUPPORTED; }
+    for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
+    if (step <= 0) step = (int)std::floor(std::sqrt(1.0 * T));        // checkpoint Viterbi.c:179-180
+    auto t0 = clk::now();
+    FV_HIP(hipSetDevice(ctx->device));
+    const int K = ctx->K, nrows = ctx->nrows;
+    const int nck = (T + step - 1) / step;
+    fv::Plan plan;
+    int rc = fv::build_plan(T, 1, FV_MODE_SINGLE_PASS, 1, plan);
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, T, (size_t)nck + 1))) return rc;  // two rows per segment + two for the first pass
+    if (ctx->d_ckpt.n < (size_t)nck * nrows) {
+        FV_HIP(ctx->d_ckpt.ensure((size_t)nck * nrows));
+        FV_HIP(hipMemsetAsync(ctx->d_ckpt.p, 0, (size_t)nck * nrows * sizeof(float), ctx->stream));   // row pads stay zero
+    }
+    const double keep_model_ms = ctx->stats.set_model_ms;
+    ctx->stats = fv_stats{};
+    ctx->stats.set_model_ms = keep_model_ms;
+    ctx->stats.kernel = FV_KERNEL_F64_STREAM;
+    ctx->stats.generations = 2;
+    ctx->stats.passes = 1 + nck;
+    ctx->stats.table_bytes_per_step = (long long)((K + fvk::TILE_W - 1) / fvk::TILE_W) * nrows * fvk::TILE_W * 8;
+    ctx->stats.density = ctx->density;
+    ctx->h_ob.assign(ob, ob + T);
+    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+
+    struct Restore { fv_ctx *c; ~Restore() { c->vanilla = 0; } } restore{ ctx };
+    ctx->vanilla = 1;
+    auto ckpt = [&](int c) { return ctx->d_ckpt.p + (size_t)c * nrows; };
+    auto scratch = [&](int q, int parity) { return ctx->d_rows.p + ((size_t)q * 2 + parity) * nrows; };
+    auto slot_for = [&](const float *in, float *out, int j) {
+        fvk::TaskSlot sl;
+        sl.t1_in = in; sl.t1_out = out;
+        sl.tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
+        sl.tmp64_row = ctx->LB64T.p + (size_t)ctx->h_ob[j] * K;
+        sl.bp_out = ctx->d_bp.p + (size_t)j * K;
+        return sl;
+    };
+    {   // initT1 (:119) into checkpoint 0
+        fvk::PassChunk ch;
+        ch.n = 1;
+        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0 };
+        hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, 1), dim3(256), 0, ctx->stream, ch, ctx->LA64.p, nrows,
+                           ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p, ctx->d_ckpt.p, K);
+        FV_HIP(hipGetLastError());
+    }
+    // first pass (:213-232)
+    auto row_after = [&](int j) -> float * { return j % step == 0 ? ckpt(j / step) : scratch(nck, j & 1); };
+    FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
+    for (int j = 1; j < T; ++j) {
+        fvk::TaskSlot sl = slot_for(row_after(j - 1), row_after(j), j);
+        if ((rc = launch_step_kernel(ctx, FV_KERNEL_F64_STREAM, &sl, 1, j & 1))) return rc;
+        ctx->stats.step_launches += 1;
+        ctx->stats.task_steps += 1;
+    }
+    FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream));
+    // second pass (:236-248, subroutine :121-174): segment c = times c*step .. min((c+1)*step, T-1)
+    std::vector<int> order(nck);
+    for (int c = 0; c < nck; ++c) order[c] = c;
+    auto seg_len = [&](int c) { return std::min((c + 1) * step, T - 1) - c * step; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return seg_len(a) > seg_len(b); });
+    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(nrows)));
+    const int maxlen = seg_len(order[0]);
+    int active = nck;
+    for (int s = 1; s <= maxlen; ++s) {
+        while (active > 0 && seg_len(order[active - 1]) < s) --active;
+        for (int base = 0; base < active; base += cap) {
+            const int nb = std::min(cap, active - base);
+            fvk::TaskSlot slots[fvk::MAX_BATCH];
+            for (int q = 0; q < nb; ++q) {
+                const int c = order[base + q];
+                slots[q] = slot_for(s == 1 ? ckpt(c) : scratch(c, (s - 1) & 1), scratch(c, s & 1), c * step + s);
+            }
+            if ((rc = launch_step_kernel(ctx, FV_KERNEL_F64_STREAM, slots, nb, s & 1))) return rc;
+            ctx->stats.step_launches += 1;
+            ctx->stats.task_steps += nb;
+        }
+    }
+    // end state (:152-165) from the first pass's last row, then the back-track through the kept arg rows (:167-171)
+    hipLaunchKernelGGL(fvk::final_argmax, dim3(1), dim3(1024), 0, ctx->stream, row_after(T - 1), K, ctx->d_ans.p + (T - 1),
+                       ctx->d_score.p);
+    FV_HIP(hipGetLastError());
+    {
+        fvk::PassChunk ch;
+        ch.n = 1;
+        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0 };
+        hipLaunchKernelGGL(fvk::backtrack, dim3(1), dim3(64), 0, ctx->stream, ch, ctx->d_bp.p, K, ctx->d_ans.p);
+        FV_HIP(hipGetLastError());
+    }
+    ctx->stats.cells = ctx->stats.task_steps * (long long)K * K;
+    ctx->stats.alg_bytes = 4 * ctx->stats.cells;
+    return finish_decode(ctx, plan, T, path_out, score_out, t0, 0, false);
+}
+
+extern "C" long long fv_checkpoint_memory_bytes(int K, int T, int step)
+{
+    if (step <= 0) step = (int)std::floor(std::sqrt(1.0 * T));
+    const long long nck = (T + step - 1) / step;
+    const long long last = T - (nck - 1) * step;
+    const long long tsub = nck > 1 && step + 1 > last ? step + 1 : last;       // T_sub, checkpoint Viterbi.c:123
+    return 4LL * K + 4LL * K * nck + 4LL * K + 4LL * (T / step + 1) + 8LL * K * tsub;   // :250
 }
 
 extern "C" int fv_last_stats(const fv_ctx *ctx, fv_stats *out)

@@ -42,7 +42,7 @@ class PassInfo(ctypes.Structure):
 
 
 EXPORTS = ["fv_create", "fv_destroy", "fv_set_model", "fv_set_option", "fv_decode_full", "fv_decode_beam",
-           "fv_decode_vanilla",
+           "fv_decode_vanilla", "fv_decode_checkpoint", "fv_checkpoint_memory_bytes",
            "fv_last_stats", "fv_strerror", "fv_last_error_detail", "fv_reference_memory_bytes",
            "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths", "fv_set_partition"]
 
@@ -68,6 +68,9 @@ def load_library():
     L.fv_decode_full.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.fv_decode_beam.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp]
     L.fv_decode_vanilla.argtypes = [vp, vp, ci, vp, vp]
+    L.fv_decode_checkpoint.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.fv_checkpoint_memory_bytes.argtypes = [ci, ci, ci]
+    L.fv_checkpoint_memory_bytes.restype = ctypes.c_longlong
     L.fv_last_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.fv_strerror.argtypes = [ci]
     L.fv_strerror.restype = ctypes.c_char_p
@@ -114,6 +117,10 @@ def merge_paths(T, n_split, nranks, gathered):
 
 def reference_memory_bytes(K, T, n_split, beam=0):
     return int(load_library().fv_reference_memory_bytes(K, T, n_split, beam))
+
+
+def checkpoint_memory_bytes(K, T, step=0):
+    return int(load_library().fv_checkpoint_memory_bytes(K, T, step))
 
 
 def _p(a):
@@ -177,6 +184,13 @@ class FlashViterbi:
         path = np.empty(ob.size, dtype=np.int32)
         score = ctypes.c_float(0)
         rc = self._check(self._L.fv_decode_vanilla(self._h, _p(ob), ob.size, _p(path), ctypes.byref(score)))
+        return path, np.float32(score.value), rc
+
+    def decode_checkpoint(self, ob, step=0):
+        ob = np.ascontiguousarray(ob, dtype=np.int32)
+        path = np.empty(ob.size, dtype=np.int32)
+        score = ctypes.c_float(0)
+        rc = self._check(self._L.fv_decode_checkpoint(self._h, _p(ob), ob.size, step, _p(path), ctypes.byref(score)))
         return path, np.float32(score.value), rc
 
     def stats(self):

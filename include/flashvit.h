@@ -132,6 +132,14 @@ int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_widt
  * divide-and-conquer schedule costs on a device where T*K back-pointers fit trivially. */
 int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_out, float *score_out);
 
+/* GPU form of Base_line/C implementations/checkpoint Viterbi.c:176-251 (viterbi_checkpoint(vit, step); step
+ * <= 0 selects floor(sqrt(T)), what its main passes): a first pass that keeps the score row of every
+ * step-th time only, then every segment re-run from its kept row with arg rows.  The arithmetic is
+ * vanilla's, so path and score equal fv_decode_vanilla's; what differs is the work (about 2x) and the
+ * memory the CPU program needs, reported by fv_checkpoint_memory_bytes as that program computes it (:250). */
+int fv_decode_checkpoint(fv_ctx *ctx, const int *ob, int T, int step, int *path_out, float *score_out);
+long long fv_checkpoint_memory_bytes(int K, int T, int step);
+
 int fv_last_stats(const fv_ctx *ctx, fv_stats *out);
 const char *fv_strerror(int rc);
 const char *fv_last_error_detail(const fv_ctx *ctx);

@@ -26,19 +26,22 @@ REF_BASE = "/root/reference/Base_line/C implementations"
 OUT = os.path.join(HERE, "_ref")
 
 SOURCES = {"flash": "FLASH_Viterbi_multithread.c", "flashbs": "FLASH_BS_Viterbi_multithread.c",
-           "vanilla": "vanilla Viterbi.c"}
+           "vanilla": "vanilla Viterbi.c", "checkpoint": "checkpoint Viterbi.c"}
+BASELINES = ("vanilla", "checkpoint")      # single-threaded programs of Base_line/: no MAX_THREADS in their config block
 
 
 def source_path(kind):
-    return os.path.join(REF_BASE if kind == "vanilla" else REF_SRC, SOURCES[kind])
+    return os.path.join(REF_BASE if kind in BASELINES else REF_SRC, SOURCES[kind])
 # gcc flags exactly as reference src/run.py:54
 GCC = ["gcc", "-g", "-pthread", "-x", "c", "-", "-lm", "-Wl,-z,stack-size=268435456"]
 
 
-def ref_name(kind, K, T, prob, N, beam=None, M=50, score=False):
+def ref_name(kind, K, T, prob, N, beam=None, M=50, score=False, step=0):
     s = f"{kind}_K{K}_T{T}_p{prob}_N{N}"
     if kind == "flashbs":
         s += f"_B{beam}"
+    if kind == "checkpoint" and step:
+        s += f"_S{step}"
     if M != 50:
         s += f"_M{M}"
     if score:
@@ -50,7 +53,7 @@ def reference_available():
     return all(os.path.isfile(source_path(k)) for k in SOURCES)
 
 
-def _patch(text, kind, K, T, prob, N, beam, M, score):
+def _patch(text, kind, K, T, prob, N, beam, M, score, step=0):
     def sub1(pat, repl, s):
         out, n = re.subn(pat, repl, s)
         if n < 1:
@@ -61,8 +64,11 @@ def _patch(text, kind, K, T, prob, N, beam, M, score):
     text = sub1(r"#define obserRouteLEN \d+", f"#define obserRouteLEN {T}", text)
     text = sub1(r"const float prob = \d+\.\d+;", f"const float prob = {prob};", text)
     text = sub1(r'const char data_path\[\] = "[^"]*";', 'const char data_path[] = "./";', text)
-    if kind != "vanilla":
+    if kind not in BASELINES:
         text = sub1(r"#define MAX_THREADS \d+", f"#define MAX_THREADS {N}", text)
+    if kind == "checkpoint" and step:
+        # main() passes 0 (= floor(sqrt(T)) inside); a fixed step is the function's own second argument
+        text = sub1(r"viterbi_checkpoint\(vit,0\);", f"viterbi_checkpoint(vit,{step});", text)
     if kind == "flashbs":
         text = sub1(r"const int BeamSearchWidth = \d+;", f"const int BeamSearchWidth = {beam};", text)
     digits = len(str(prob).split(".")[1]) if "." in str(prob) else 0
@@ -71,6 +77,8 @@ def _patch(text, kind, K, T, prob, N, beam, M, score):
         # after the whole-sequence end-state pick ("vit->Ans[R] = arg;" / "... .State;")
         if kind == "vanilla":
             text = sub1(r"(vit->Ans\[obserRouteLEN-1\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)tmp);', text)
+        elif kind == "checkpoint":
+            text = sub1(r"(vit->Ans\[\(\*count\)--\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)tmp);', text)
         elif kind == "flash":
             text = sub1(r"(vit->Ans\[R\] = arg;)", r'\1 fprintf(stderr, "score: %.9g\\n", (double)score);', text)
         else:
@@ -79,17 +87,17 @@ def _patch(text, kind, K, T, prob, N, beam, M, score):
     return text
 
 
-def build(kind, K, T, prob, N, beam=None, M=50, score=False, force=False):
+def build(kind, K, T, prob, N, beam=None, M=50, score=False, force=False, step=0):
     """Returns the path of the binary, building it if the reference tree is present.
     Raises FileNotFoundError when neither the binary nor the reference exists."""
     os.makedirs(OUT, exist_ok=True)
-    exe = os.path.join(OUT, ref_name(kind, K, T, prob, N, beam, M, score))
+    exe = os.path.join(OUT, ref_name(kind, K, T, prob, N, beam, M, score, step))
     if os.path.isfile(exe) and not force:
         return exe
     if not reference_available():
         raise FileNotFoundError(f"{exe} not prebuilt and {REF_SRC} is absent")
     with open(source_path(kind), "r") as f:
-        text = _patch(f.read(), kind, K, T, prob, N, beam, M, score)
+        text = _patch(f.read(), kind, K, T, prob, N, beam, M, score, step)
     res = subprocess.run(GCC + ["-o", exe], input=text, text=True, capture_output=True)
     if res.returncode != 0:
         raise RuntimeError(f"gcc failed for {exe}:\n{res.stderr}")

@@ -346,6 +346,93 @@ int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, floa
     return rc;
 }
 
+/* ------------------------------------------------------------ checkpoint -- */
+
+/* One vanilla step (checkpoint Viterbi.c:132-148 with T2, :216-226 without): out[i] = max_k
+ * (float)(((double)in[k] + log A[k][i]) + log B[i][o]) from (-FLT_MAX, -1), strict '>' in ascending k.
+ * The arg-free form of the first pass calls emax(float, float) (:29-32, :222): the double expression is
+ * rounded to float at the call, so it holds the same values. */
+static void vanilla_step(const fvo_model *m, int o, const float *in, float *out, int *arg_row)
+{
+    const int K = m->K, M = m->M;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < K; ++i) {
+        const double *col = m->logAT + (size_t)i * K;
+        const double lb = m->logB[(size_t)i * M + o];
+        float tmp = -FLT_MAX;
+        int arg = -1;
+        for (int k = 0; k < K; ++k) {
+            float tmp2 = (float)(((double)in[k] + col[k]) + lb);
+            if (tmp2 > tmp) { tmp = tmp2; arg = k; }
+        }
+        out[i] = tmp;
+        if (arg_row) arg_row[i] = arg;
+    }
+}
+
+/* viterbi_checkpoint() of Base_line/C implementations/checkpoint Viterbi.c:176-251 with `step` as its
+ * second argument (main passes 0 => floor(sqrt(T)), :179-180).  First pass (:183-232): the score row
+ * after every time j that is a multiple of `step` is kept (checkpoints 0, step, 2*step, ... < T).
+ * Second pass, last checkpoint first (:236-248): viterbi_checkpoint_subroutine (:121-174) re-runs the
+ * recurrence from the kept row over its segment — up to and including the next checkpoint's time, or to
+ * T-1 for the last one — this time with arg rows, picks the end state (last segment only, :152-165) and
+ * back-tracks through the segment (:167-171). */
+int fvo_checkpoint_decode(const fvo_model *m, const int *ob, int T, int step, int *path, float *score)
+{
+    if (!m || !ob || !path || T < 1) return FVO_ERR_ARG;
+    for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= m->M) return FVO_ERR_ARG;
+    if (step <= 0) step = (int)floor(sqrt(1.0 * T));
+    const int K = m->K;
+    const int nck = (T + step - 1) / step;
+    float *ck = (float *)malloc(sizeof(float) * (size_t)K * nck);
+    float *a = (float *)malloc(sizeof(float) * K), *b = (float *)malloc(sizeof(float) * K);
+    int *T2 = (int *)malloc(sizeof(int) * (size_t)K * (step + 1));
+    if (!ck || !a || !b || !T2) { free(ck); free(a); free(b); free(T2); return FVO_ERR_NOMEM; }
+    full_init_row(m, ob[0], -1, a);                                  /* initT1, :119 */
+    memcpy(ck, a, sizeof(float) * K);
+    for (int j = 1; j < T; ++j) {
+        vanilla_step(m, ob[j], a, b, NULL);
+        float *t = a; a = b; b = t;
+        if (j % step == 0) memcpy(ck + (size_t)(j / step) * K, a, sizeof(float) * K);
+    }
+    int rc = 0, count = T - 1;
+    for (int c = nck - 1; c >= 0 && !rc; --c) {
+        const int start = c * step;
+        const int tsub = (c == nck - 1) ? T - start : step + 1;       /* T_sub, :123 */
+        memcpy(a, ck + (size_t)c * K, sizeof(float) * K);
+        for (int j = 1; j < tsub; ++j) {
+            vanilla_step(m, ob[start + j], a, b, T2 + (size_t)j * K);
+            float *t = a; a = b; b = t;
+        }
+        if (c == nck - 1) {
+            float tmp = -FLT_MAX;
+            int arg = -1;
+            for (int k = 0; k < K; ++k) if (a[k] > tmp) { tmp = a[k]; arg = k; }
+            if (score) *score = tmp;
+            if (arg < 0) { rc = FVO_ERR_NO_PRED; path[count] = arg; break; }
+            path[count--] = arg;
+        }
+        for (int i = tsub - 1; i > 0; --i) {
+            path[count] = T2[(size_t)i * K + path[count + 1]];
+            if (path[count] < 0) { rc = FVO_ERR_NO_PRED; break; }
+            count--;
+        }
+    }
+    free(ck); free(a); free(b); free(T2);
+    return rc;
+}
+
+/* memory_bytes of the same program (:250): T1_previous + T1[K][checkpointslen] + T1_current +
+ * checkpoints[T/step+1] + the largest sizeof(T1_sub)+sizeof(T2_sub) of the subroutine (:173). */
+long long fvo_checkpoint_memory_bytes(int K, int T, int step)
+{
+    if (step <= 0) step = (int)floor(sqrt(1.0 * T));
+    const long long nck = (T + step - 1) / step;
+    const long long last = T - (nck - 1) * step;
+    const long long tsub = nck > 1 && step + 1 > last ? step + 1 : last;
+    return 4LL * K + 4LL * K * nck + 4LL * K + 4LL * (T / step + 1) + 8LL * K * tsub;
+}
+
 /* ------------------------------------------------------------------ beam -- */
 
 /* FLASH_BS:51-56.  Slot 0's .value carries the element count as a float. */

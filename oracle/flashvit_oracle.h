@@ -51,6 +51,11 @@ int fvo_beam_decode(const fvo_model *m, const int *ob, int T, int n_split, int b
  * output of its checkpoint Viterbi.c: same recurrence, different memory schedule). */
 int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, float *score);
 
+/* viterbi_checkpoint(vit, step) of Base_line/C implementations/checkpoint Viterbi.c:176-251 (step <= 0:
+ * floor(sqrt(T)), as its main does) and the memory_bytes it reports (:250). */
+int fvo_checkpoint_decode(const fvo_model *m, const int *ob, int T, int step, int *path, float *score);
+long long fvo_checkpoint_memory_bytes(int K, int T, int step);
+
 /* One plain forward pass over [L,R] (nvviter's recurrence, :204-246) that keeps
  * every arg row: score_row[K] = T1 after the last step, argtab[(R-L)*K] = arg of
  * step j at row j-L-1 (-1 where no finite predecessor).  init_state < 0 => start

@@ -47,6 +47,9 @@ def lib():
         L.fvo_beam_decode.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp]
         L.fvo_full_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
         L.fvo_vanilla_decode.argtypes = [vp, vp, ci, vp, vp]
+        L.fvo_checkpoint_decode.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.fvo_checkpoint_memory_bytes.argtypes = [ci, ci, ci]
+        L.fvo_checkpoint_memory_bytes.restype = ctypes.c_longlong
         L.fvo_set_threads.argtypes = [ci]
         L.fvo_full_memory_bytes.restype = ctypes.c_longlong
         L.fvo_full_memory_bytes.argtypes = [ci, ci, ci]
@@ -122,6 +125,15 @@ class OracleModel:
             raise OracleError(rc)
         return path, np.float32(score.value), rc
 
+    def checkpoint_decode(self, ob, step=0, check=True):
+        ob = np.ascontiguousarray(ob, dtype=np.int32)
+        path = np.empty(ob.size, dtype=np.int32)
+        score = ctypes.c_float(0)
+        rc = lib().fvo_checkpoint_decode(self._h, _p(ob), ob.size, step, _p(path), ctypes.byref(score))
+        if rc < 0 and check:
+            raise OracleError(rc)
+        return path, np.float32(score.value), rc
+
     def full_forward(self, ob, L, R, init_state=-1):
         ob = np.ascontiguousarray(ob, dtype=np.int32)
         row = np.empty(self.K, dtype=np.float32)
@@ -130,6 +142,10 @@ class OracleModel:
         if rc:
             raise OracleError(rc)
         return row, args
+
+
+def checkpoint_memory_bytes(K, T, step=0):
+    return int(lib().fvo_checkpoint_memory_bytes(K, T, step))
 
 
 def full_memory_bytes(K, T, n_split):

@@ -36,7 +36,7 @@ def golden_runs(include_big=False, algo=None):
             if algo and r["algo"] != algo:
                 continue
             pairs.append((g, r))
-            ids.append(f"{g['name']}-{r['algo']}-N{r['N']}" + (f"-B{r['B']}" if "B" in r else ""))
+            ids.append(f"{g['name']}-{r['algo']}-N{r['N']}" + (f"-B{r['B']}" if "B" in r else "") + (f"-S{r['step']}" if "step" in r else ""))
     return pairs, ids
 
 

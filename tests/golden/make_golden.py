@@ -11,6 +11,7 @@ fprintf, see build_ref.py) the whole-sequence final score.
 
   python3 tests/golden/make_golden.py            # all small cases
   python3 tests/golden/make_golden.py --big      # also K=3965 (minutes of CPU)
+  python3 tests/golden/make_golden.py --append   # keep the recorded runs, execute only new ones
 """
 import json
 import os
@@ -34,40 +35,51 @@ OB_CFG2 = [int(x) for x in """15 16 18 9 27 30 26 28 18 19 41 23 18 14 16 25 26 
 F = lambda *ns: [dict(algo="flash", N=n) for n in ns]
 BS = lambda *nb: [dict(algo="flashbs", N=n, B=b) for n, b in nb]
 V = [dict(algo="vanilla", N=1)]     # Base_line/C implementations/vanilla Viterbi.c (cross-check baseline)
+C = lambda *steps: [dict(algo="checkpoint", N=1, step=st) for st in steps]   # .../checkpoint Viterbi.c; step 0 = floor(sqrt(T)), its main's choice
 
 CASES = [
     dict(name="cfg1_K128_T256", spec=dict(kind="data_script", K=128, M=50, T=256, prob=0.253, seed=12, ob=OB_CFG1),
-         runs=F(1, 4, 8) + BS((1, 32), (2, 32), (3, 32), (4, 32), (8, 32), (16, 32), (4, 64), (4, 128)) + V),
+         runs=F(1, 4, 8) + BS((1, 32), (2, 32), (3, 32), (4, 32), (8, 32), (16, 32), (4, 64), (4, 128)) + V + C(0, 100)),
     dict(name="ds_K200_T100", spec=dict(kind="data_script", K=200, M=50, T=100, prob=0.1, seed=3),
-         runs=F(1, 3, 5, 7) + BS((1, 16), (3, 17), (5, 50), (4, 200)) + V),
+         runs=F(1, 3, 5, 7) + BS((1, 16), (3, 17), (5, 50), (4, 200)) + V + C(0, 7, 99)),
     dict(name="ds_K77_M7_T33", spec=dict(kind="data_script", K=77, M=7, T=33, prob=0.3, seed=5),
-         runs=F(1, 2, 3, 4) + BS((1, 8), (3, 9), (4, 77)) + V),
+         runs=F(1, 2, 3, 4) + BS((1, 8), (3, 9), (4, 77)) + V + C(0, 1, 4, 33, 40)),
     dict(name="ds_K512_T64", spec=dict(kind="data_script", K=512, M=50, T=64, prob=0.05, seed=7),
          runs=F(1, 8) + BS((8, 64), (1, 100))),
-    dict(name="ds_K5_T2", spec=dict(kind="data_script", K=5, M=3, T=2, prob=0.9, seed=1), runs=F(1) + BS((1, 2), (1, 5)) + V),
+    dict(name="ds_K5_T2", spec=dict(kind="data_script", K=5, M=3, T=2, prob=0.9, seed=1), runs=F(1) + BS((1, 2), (1, 5)) + V + C(0)),
     dict(name="ds_K5_T3", spec=dict(kind="data_script", K=5, M=3, T=3, prob=0.9, seed=2), runs=F(1, 2) + BS((1, 3))),
     dict(name="ds_K9_T7", spec=dict(kind="data_script", K=9, M=3, T=7, prob=0.8, seed=4), runs=F(1, 3) + BS((1, 4), (3, 4))),
     dict(name="ties_all_K64_T64", spec=dict(kind="ties_all", K=64, M=4, T=64, prob=0.5, seed=21),
-         runs=F(1, 4) + BS((1, 8), (4, 16), (3, 64)) + V),
+         runs=F(1, 4) + BS((1, 8), (4, 16), (3, 64)) + V + C(0, 3)),
     dict(name="ties_semi_K96_T80", spec=dict(kind="ties_semi", K=96, M=4, T=80, prob=0.5, seed=22),
-         runs=F(1, 3, 8) + BS((1, 12), (4, 32), (8, 33)) + V),
+         runs=F(1, 3, 8) + BS((1, 12), (4, 32), (8, 33)) + V + C(0, 16)),
 ]
 BIG_CASES = [
     dict(name="cfg2_K3965_T256", spec=dict(kind="data_script", K=3965, M=50, T=256, prob=0.112, seed=12, ob=OB_CFG2),
-         runs=F(8) + BS((8, 32), (8, 256)) + V),
+         runs=F(8) + BS((8, 32), (8, 256)) + V + C(0)),
 ]
 
 
-def make_case(case, keep_dir=None):
+def run_key(r):
+    return (r["algo"], r["N"], r.get("B"), r.get("step"))
+
+
+def make_case(case, keep_dir=None, have=None):
+    """have: runs already recorded for this case (--append): kept as they are, only the missing ones are executed."""
     spec = case["spec"]
     tmp = keep_dir or tempfile.mkdtemp(prefix="fvgold_")
     try:
         modelgen.write_text(spec, tmp)
         A, B, Pi, ob = modelgen.model32(spec)
         runs = []
+        done = {run_key(r): r for r in (have or [])}
         for r in case["runs"]:
+            if run_key(r) in done:
+                runs.append(done[run_key(r)])
+                continue
             kind = r["algo"]
-            exe = build_ref.build(kind, spec["K"], spec["T"], spec["prob"], r["N"], r.get("B"), M=spec["M"], score=True)
+            exe = build_ref.build(kind, spec["K"], spec["T"], spec["prob"], r["N"], r.get("B"), M=spec["M"], score=True,
+                                  step=r.get("step", 0))
             out = build_ref.run(exe, tmp)
             rec = dict(r)
             rec.update(path=out["path"], memory=out["memory"], score=out["score"], ref_time_s=out["time"])
@@ -88,8 +100,13 @@ def main():
         cases = BIG_CASES if "--only-big" in sys.argv else cases + BIG_CASES
     for case in cases:
         print(case["name"])
-        rec = make_case(case)
-        with open(os.path.join(HERE, case["name"] + ".json"), "w") as f:
+        path = os.path.join(HERE, case["name"] + ".json")
+        have = None
+        if "--append" in sys.argv and os.path.isfile(path):
+            with open(path) as f:
+                have = json.load(f)["runs"]
+        rec = make_case(case, have=have)
+        with open(path, "w") as f:
             json.dump(rec, f, separators=(",", ":"))
             f.write("\n")
 

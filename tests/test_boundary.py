@@ -108,7 +108,9 @@ def test_memory_formula_matches_reference_printout():
     for g in load_goldens(include_big=True):
         K, T = g["spec"]["K"], g["spec"]["T"]
         for r in g["runs"]:
-            if r["algo"] != "vanilla":
+            if r["algo"] == "checkpoint":
+                assert decoder.checkpoint_memory_bytes(K, T, r["step"]) == r["memory"]
+            elif r["algo"] != "vanilla":
                 assert decoder.reference_memory_bytes(K, T, r["N"], r.get("B", 0)) == r["memory"]
 
 

@@ -144,6 +144,36 @@ def test_vanilla_baseline_matches_reference_vanilla_binary(ctxs, g, r):
     assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
 
 
+CPAIRS, CIDS = golden_runs(include_big=True, algo="checkpoint")
+
+
+@pytest.mark.parametrize("g,r", CPAIRS, ids=CIDS)
+def test_checkpoint_baseline_matches_reference_checkpoint_binary(ctxs, g, r):
+    """fv_decode_checkpoint against goldens from Base_line/C implementations/checkpoint Viterbi.c
+    (step 0 = floor(sqrt(T)), what its main passes; other steps through the function's own argument)."""
+    fv, ob = ctxs(g)
+    path, score, rc = fv.decode_checkpoint(ob, r["step"])
+    assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+    assert decoder.checkpoint_memory_bytes(fv.K, len(ob), r["step"]) == r["memory"]
+
+
+@pytest.mark.parametrize("step", [0, 1, 2, 9, 10, 89, 90, 500])
+def test_checkpoint_equals_vanilla_and_oracle_for_every_step(step):
+    """Segment lengths 1, ragged last segment, one segment only (step >= T): same bits as vanilla."""
+    import modelgen
+    spec = dict(kind="data_script", K=300, M=9, T=90, prob=0.15, seed=311)
+    A, B, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, B, Pi)
+    cp, cs, _ = om.checkpoint_decode(ob, step)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    vpath, vscore, _ = fv.decode_vanilla(ob)
+    path, score, rc = fv.decode_checkpoint(ob, step)
+    assert rc == 0 and path.tolist() == cp.tolist() and score == cs
+    assert path.tolist() == vpath.tolist() and score == vscore
+    fv.close()
+
+
 def test_vanilla_matches_oracle_and_flash_path_on_fresh_input():
     import modelgen
     spec = dict(kind="data_script", K=700, M=13, T=90, prob=0.1, seed=301)

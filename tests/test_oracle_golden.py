@@ -18,6 +18,9 @@ def test_oracle_matches_reference_binary(g, r):
     if r["algo"] == "vanilla":
         path, score, rc = m.vanilla_decode(ob)
         mem = m.K * T * 8        # sizeof(T1)+sizeof(T2), vanilla Viterbi.c:172
+    elif r["algo"] == "checkpoint":
+        path, score, rc = m.checkpoint_decode(ob, r["step"])
+        mem = oracle.checkpoint_memory_bytes(m.K, T, r["step"])     # checkpoint Viterbi.c:250
     elif r["algo"] == "flash":
         path, score, cells, rc = m.full_decode(ob, r["N"])
         mem = oracle.full_memory_bytes(m.K, T, r["N"])

@@ -9,8 +9,8 @@ A, B, Pi, ob = modelgen.model32(g["spec"])
 ref = g["runs"][0]
 fv = decoder.FlashViterbi(0)
 fv.set_model(A, B, Pi)
-for kern in (4, 2, 3):
-    for dbg in (0,):
+for kern in ([int(x) for x in os.environ.get("FV_KERNS", "4,2,3").split(",")]):
+    for dbg in ([int(x) for x in os.environ.get("FV_DBGS", "0").split(",")]):
         for mb in (4, 8):
             fv.set_option(decoder.OPT_KERNEL, kern); fv.set_option(decoder.OPT_DEBUG, dbg); fv.set_option(decoder.OPT_MAX_BATCH, mb)
             best = None

@@ -71,6 +71,8 @@ struct fv_ctx {
     DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
     DevBuf<int> d_hstate, d_slot_state, d_flags;
     DevBuf<double> LA64R;                            // row-gather copy of the float64 table (built on first beam decode)
+    DevBuf<unsigned short> LAQ16R;                   // row-major fixed-point table of beam_step_q16 (same moment; only when every log <= 0)
+    DevBuf<unsigned long long> d_qaux;               // [0] lmax bits, [1] dmax bits, then {qscale, window} as floats (q16_params)
     DevBuf<int2> d_tie_list;
     DevBuf<float> d_cut;         // [T][2] theta and duplicate flag of every step's heap
     DevBuf<int> d_dupwin;        // [T]
@@ -112,7 +114,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -531,7 +533,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -712,7 +714,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok;
-    ctx->LA64R.release();                 // rebuilt from the new table on the next beam decode
+    ctx->LA64R.release(); ctx->LAQ16R.release();      // rebuilt from the new table on the next beam decode
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = ms_since(t0);
@@ -792,6 +794,7 @@ namespace {
 
 // row pitch of the row-major float64 table the beam kernels gather from
 inline int beam_ld(int K) { return (K + fvb::BEAM_COLS - 1) / fvb::BEAM_COLS * fvb::BEAM_COLS; }
+inline int beam_ldq(int K) { return (K + fvb::BEAMQ_COLS - 1) / fvb::BEAMQ_COLS * fvb::BEAMQ_COLS; }   // ... of the 16-bit one
 
 // One generation of beam passes in lock-step (same shape as run_generation_full).  Buffers are indexed
 // by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
@@ -844,7 +847,8 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
             a.tie_cap = (unsigned int)ctx->d_tie_list.n;
             a.counters = ctx->d_counters.p;
-            a.K = K; a.ld = beam_ld(K); a.beam = beam;
+            a.K = K; a.ld = beam_ld(K); a.ldq = beam_ldq(K); a.beam = beam;
+            a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->LAQ16R.p ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
@@ -857,8 +861,18 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * 2;
                 a.p[q].dupwin = ctx->d_dupwin.p + j;
             }
-            hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
-                               ctx->stream, a);
+            // The 16-bit filter kernel moves a quarter of the bytes but has two more dependent phases (window,
+            // float64 refine): measured at K = 16384, B = 256 it takes 13.7 us + 2.6 us per extra pass of the
+            // launch against 10.6 + 5.0 for the float64 kernel, so it is used from ~80 MB of float64 rows per
+            // launch on (cfg5: 537 MB per pass).  FV_OPT_DEBUG bit 8: never, bit 9: always.
+            const bool use_q16 = ctx->LAQ16R.p && !(ctx->opt_debug & 256) &&
+                                 ((ctx->opt_debug & 512) || (double)a.n * beam * K * 8.0 >= 80e6);
+            if (use_q16)
+                hipLaunchKernelGGL(fvb::beam_step_q16, dim3(beam_ldq(K) / fvb::BEAMQ_COLS, a.n), dim3(fvb::BEAM_BLOCK),
+                                   fvb::beam_step_q16_lds(beam), ctx->stream, a);
+            else
+                hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
+                                   ctx->stream, a);
             FV_HIP(hipGetLastError());
             ctx->stats.step_launches += 1;
             ctx->stats.task_steps += a.n;
@@ -909,7 +923,8 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     if (ctx->K == 0) return FV_ERR_STATE;
     // beam > K reads uninitialised heap slots in the reference
     if (beam_width < 2 || beam_width > ctx->K) return FV_ERR_ARG;
-    if (fvb::beam_step_lds(beam_width) > 150 * 1024 || fvb::heap_lds(beam_width) > 150 * 1024) return FV_ERR_UNSUPPORTED;
+    if (fvb::beam_step_lds(beam_width) > 150 * 1024 || fvb::beam_step_q16_lds(beam_width) > 150 * 1024 ||
+        fvb::heap_lds(beam_width) > 150 * 1024) return FV_ERR_UNSUPPORTED;
     if (ctx->K > fvb::SEL_MAX_ROUNDS * fvb::SEL_BLOCK) return FV_ERR_UNSUPPORTED;      // topb_select: one bit per round
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     auto t0 = clk::now();
@@ -938,6 +953,19 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
         const int ld = beam_ld(ctx->K);
         FV_HIP(ctx->LA64R.ensure((size_t)ctx->K * ld));
         hipLaunchKernelGGL(fvb::relayout_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LA64R.p, ctx->K, ctx->nrows, ld);
+        FV_HIP(hipGetLastError());
+    }
+    if (!ctx->LAQ16R.p && ctx->logs_nonpositive) {
+        // filter table of beam_step_q16, quantised on the device from LA64R
+        const int ld = beam_ld(ctx->K), ldq = beam_ldq(ctx->K);
+        FV_HIP(ctx->LAQ16R.ensure((size_t)ctx->K * ldq));
+        FV_HIP(ctx->d_qaux.ensure(3));
+        FV_HIP(hipMemsetAsync(ctx->d_qaux.p, 0, 3 * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(fvb::q16_range, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64R.p, (size_t)ctx->K * ld, ctx->d_qaux.p);
+        hipLaunchKernelGGL(fvb::q16_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64R.p, ctx->LAQ16R.p, ctx->K, ld, ldq,
+                           ctx->d_qaux.p, ctx->d_qaux.p + 1);
+        hipLaunchKernelGGL(fvb::q16_params, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qaux.p, ctx->d_qaux.p + 1,
+                           reinterpret_cast<float *>(ctx->d_qaux.p + 2));
         FV_HIP(hipGetLastError());
     }
 

@@ -41,6 +41,21 @@ def test_beam_reference_mode_matches_golden(ctxs, g, r):
     assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"], r["B"]) == r["memory"]
 
 
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_beam_q16_filter_kernel_matches_golden(ctxs, g, r):
+    """FV_OPT_DEBUG bit 9 forces beam_step_q16 (filter on the 16-bit table + float64 refine), which the
+    library otherwise uses for large launches only; bit 8 forces the float64 kernel."""
+    fv, ob = ctxs(g)
+    for dbg in (512, 256):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert path.tolist() == r["path"] and score == np.float32(r["score"])
+        assert rc == (decoder.WARN_BEAM_MISS if -1 in r["path"] else 0)
+
+
 @pytest.mark.parametrize("K,M,T,N,B,seed,prob", [(300, 11, 70, 4, 20, 201, 0.15), (1000, 50, 40, 3, 128, 202, 0.1),
                                                  (65, 5, 129, 8, 65, 203, 0.3), (2049, 20, 24, 1, 500, 204, 0.05),
                                                  (130, 4, 90, 16, 2, 205, 0.5), (700, 9, 33, 5, 699, 206, 0.2),
@@ -54,8 +69,10 @@ def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    path, score, rc = fv.decode_beam(ob, N, B)
-    assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+    for dbg in (0, 512):            # library's choice of beam step kernel, then the 16-bit filter kernel forced
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        path, score, rc = fv.decode_beam(ob, N, B)
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc
     fv.close()
 
 

@@ -83,7 +83,8 @@ struct fv_ctx {
     int opt_max_batch = fvk::MAX_BATCH;
     int opt_profile = 0;
     int vanilla = 0;         // set for the duration of fv_decode_vanilla
-    int opt_debug = 0;       // FV_OPT_DEBUG bits: 1 skip refine (timing only), 2 no reverse sweep, 4 alternate unroll
+    int opt_debug = 0;       // FV_OPT_DEBUG bits: 1 skip refine (timing only), 2 no reverse sweep, 4 alternate unroll, 8 full last step,
+                             // 16 launch only / 32 no score-row staging (sparse walk), 64 hipGraph replay, 256 / 512 beam step kernel: float64 / 16-bit
     std::vector<hipEvent_t> prof_events;
     std::vector<int> h_ob;
     std::vector<hipGraphExec_t> graphs;     // experiment (FV_OPT_DEBUG bit 6): destroyed after the decode's sync

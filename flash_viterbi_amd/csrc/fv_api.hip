@@ -47,6 +47,7 @@ struct DevBuf {
 struct fv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    int num_cus = 256;       // multiProcessorCount of the device (MI355X: 256)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     std::string detail;
 
@@ -199,9 +200,12 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
         return launch_variant<TA, NB, U_DB32, true>(ctx, a, lds);
     } else {
         // 16-bit tables: an XCD's slab (3.9 MB at K=3965) nearly fits its L2, so requesting the whole
-        // tile before staging the score row wins (9.5 vs 9.8 us/step); FV_OPT_DEBUG bit 2 turns it off
+        // tile before staging the score row wins (9.5 vs 9.8 us/step); FV_OPT_DEBUG bit 2 turns it off.
+        // That variant holds the tile in 86 VGPRs: one workgroup per CU.  With more tiles than CUs the
+        // double-buffered one (46 VGPRs, two workgroups per CU) keeps the grid in one round
+        // (K=5632: 18.3 vs 25.3 us/step, K=8192: 25.8 vs 39.8).
         if constexpr (NB <= 2) {
-            if (nj_max <= U_UP && !(ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
+            if (nj_max <= U_UP && a.ntiles <= ctx->num_cus && !(ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
         }
         return launch_variant<TA, NB, U_DB16, true>(ctx, a, lds);
     }
@@ -504,6 +508,10 @@ extern "C" int fv_create(fv_ctx **out, int device)
     auto fail = [&](int rc) { fv_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(FV_ERR_DEVICE);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(FV_ERR_DEVICE);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
     if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
         hipEventCreate(&ctx->ev_top) != hipSuccess || hipEventCreate(&ctx->ev_s0) != hipSuccess ||
         hipEventCreate(&ctx->ev_s1) != hipSuccess)

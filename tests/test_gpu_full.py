@@ -61,7 +61,9 @@ def test_single_pass_mode_matches_golden_empirically(ctxs, g, r):
 
 @pytest.mark.parametrize("K,M,T,N,seed,prob", [(300, 11, 70, 4, 101, 0.15), (1000, 50, 40, 3, 102, 0.15),
                                                (65, 5, 129, 8, 103, 0.15), (2049, 20, 24, 1, 104, 0.15),
-                                               (16, 3, 200, 16, 105, 0.8)])
+                                               (16, 3, 200, 16, 105, 0.8),
+                                               # more 16-column tiles than CUs: the two-workgroups-per-CU variant
+                                               (4500, 12, 14, 3, 106, 0.05)])
 def test_reference_mode_matches_oracle_fresh_inputs(K, M, T, N, seed, prob):
     import modelgen
     spec = dict(kind="data_script", K=K, M=M, T=T, prob=prob, seed=seed)

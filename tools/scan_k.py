@@ -15,6 +15,7 @@ for K in Ks:
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, B, Pi)
     fv.set_option(decoder.OPT_KERNEL, kern)
+    fv.set_option(decoder.OPT_DEBUG, int(os.environ.get("FV_DEBUG", "0")))
     best = None
     for rep in range(6):
         fv.decode_full(ob, 1, decoder.MODE_SINGLE_PASS)

@@ -238,6 +238,19 @@ def main():
         }
         if sparse is not None:
             line["sparse_walk"] = sparse
+        if args.gpus == 1:
+            # extra: the FLASH-BS variant on the same model (never part of `value`)
+            BEAM = 256
+            fv.decode_beam(ob, N_SPLIT, BEAM)
+            tb = time.perf_counter()
+            nbs = 5
+            for _ in range(nbs):
+                _, _, brc = fv.decode_beam(ob, N_SPLIT, BEAM)
+            bdt = (time.perf_counter() - tb) / nbs
+            bst = fv.stats()
+            line["flash_bs"] = {"workload": f"FLASH-BS K={K} T={T} n_split={N_SPLIT} beam={BEAM}, same model", "decode_ms": 1e3 * bdt,
+                                "beam_cells_per_sec": K * BEAM * T / bdt, "exact_heap_replays_on_critical_path": bst["beam_exact_sets"],
+                                "rc": int(brc)}
         if args.gpus == 1 and not args.no_cpu_baseline:
             hip_sample, _, _ = fv.decode_full(ob[:CPU_SAMPLE_T], CPU_THREADS, decoder.MODE_REFERENCE)
             line["cpu_baseline"] = cpu_baseline(model64, ob, hip_sample.tolist())

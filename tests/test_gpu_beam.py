@@ -76,6 +76,26 @@ def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
     fv.close()
 
 
+@pytest.mark.parametrize("kind,K,M,T,N,B,seed", [("ties_semi", 1200, 4, 40, 4, 50, 221), ("ties_all", 600, 4, 30, 3, 33, 222),
+                                                 ("ties_semi", 5000, 4, 16, 1, 200, 223)])
+def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
+    """Few distinct probabilities => many equal scores: nearly every selection has duplicates at the cut (exact heap
+    replay inside topb_select), many cells have tied maxima (tie_fixup), beam misses occur."""
+    import modelgen
+    spec = dict(kind=kind, K=K, M=M, T=T, prob=0.5, seed=seed)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, N, B)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    for dbg in (0, 512):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        path, score, rc = fv.decode_beam(ob, N, B)
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+    assert fv.stats()["beam_exact_sets"] > 0
+    fv.close()
+
+
 def test_beam_equal_to_K_is_full_decode():
     """B = K keeps every state: same path and score as the full-state decoder."""
     import modelgen

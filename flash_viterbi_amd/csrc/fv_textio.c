@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "flashvit_host.h"
 
@@ -151,7 +152,8 @@ int fvh_read_ints_text(const char *path, int *out, size_t n)
 
 /* Raw little-endian f32 / i32 cache files ("binary model cache"):
  * 16-byte header {magic, dtype, rows, cols} then the payload. */
-#define FVH_MAGIC 0x31425646u /* "FVB1" */
+#define FVH_MAGIC 0x31425646u  /* "FVB1" */
+#define FVH_MAGIC2 0x32425646u /* "FVB2": + {uint64 size, uint64 mtime in ns} of the text file the payload was parsed from */
 
 int fvh_write_bin(const char *path, const void *data, uint32_t dtype, uint32_t rows, uint32_t cols)
 {
@@ -166,17 +168,73 @@ int fvh_write_bin(const char *path, const void *data, uint32_t dtype, uint32_t r
     return rc;
 }
 
+/* Header of either version; *src_size / *src_mtime_ns stay 0 for an unbound (FVB1) file. */
+static int read_bin_header(FILE *fp, uint32_t dtype, uint32_t rows, uint32_t cols, uint64_t *src_size, uint64_t *src_mtime_ns)
+{
+    uint32_t hdr[4];
+    *src_size = *src_mtime_ns = 0;
+    if (fread(hdr, sizeof hdr, 1, fp) != 1) return FVH_ERR_READ;
+    if ((hdr[0] != FVH_MAGIC && hdr[0] != FVH_MAGIC2) || hdr[1] != dtype || hdr[2] != rows || hdr[3] != cols)
+        return FVH_ERR_FORMAT;
+    if (hdr[0] == FVH_MAGIC2) {
+        uint64_t src[2];
+        if (fread(src, sizeof src, 1, fp) != 1) return FVH_ERR_READ;
+        *src_size = src[0]; *src_mtime_ns = src[1];
+    }
+    return 0;
+}
+
 int fvh_read_bin(const char *path, void *data, uint32_t dtype, uint32_t rows, uint32_t cols)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) return FVH_ERR_OPEN;
-    uint32_t hdr[4];
+    size_t n = (size_t)rows * cols;
+    uint64_t a, b;
+    int rc = read_bin_header(fp, dtype, rows, cols, &a, &b);
+    if (!rc && n && fread(data, 4, n, fp) != n) rc = FVH_ERR_SHORT;
+    fclose(fp);
+    return rc;
+}
+
+/* Size and modification time of the text file a cache was parsed from (0, 0 when it does not exist). */
+static int stat_source(const char *src, uint64_t *size, uint64_t *mtime_ns)
+{
+    struct stat sb;
+    *size = *mtime_ns = 0;
+    if (!src || stat(src, &sb) != 0) return -1;
+    *size = (uint64_t)sb.st_size;
+    *mtime_ns = (uint64_t)sb.st_mtim.tv_sec * 1000000000ull + (uint64_t)sb.st_mtim.tv_nsec;
+    return 0;
+}
+
+int fvh_write_bin_src(const char *path, const void *data, uint32_t dtype, uint32_t rows, uint32_t cols,
+                      const char *src_text_path)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return FVH_ERR_OPEN;
+    uint32_t hdr[4] = { FVH_MAGIC2, dtype, rows, cols };
+    uint64_t src[2];
+    (void)stat_source(src_text_path, &src[0], &src[1]);
     size_t n = (size_t)rows * cols;
     int rc = 0;
-    if (fread(hdr, sizeof hdr, 1, fp) != 1) rc = FVH_ERR_READ;
-    else if (hdr[0] != FVH_MAGIC || hdr[1] != dtype || hdr[2] != rows || hdr[3] != cols)
-        rc = FVH_ERR_FORMAT;
-    else if (n && fread(data, 4, n, fp) != n) rc = FVH_ERR_SHORT;
+    if (fwrite(hdr, sizeof hdr, 1, fp) != 1 || fwrite(src, sizeof src, 1, fp) != 1) rc = FVH_ERR_WRITE;
+    if (!rc && n && fwrite(data, 4, n, fp) != n) rc = FVH_ERR_WRITE;
+    if (fclose(fp) != 0 && !rc) rc = FVH_ERR_WRITE;
+    return rc;
+}
+
+int fvh_read_bin_src(const char *path, void *data, uint32_t dtype, uint32_t rows, uint32_t cols,
+                     const char *src_text_path)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return FVH_ERR_OPEN;
+    size_t n = (size_t)rows * cols;
+    uint64_t have_size, have_mtime, want_size, want_mtime;
+    int rc = read_bin_header(fp, dtype, rows, cols, &have_size, &have_mtime);
+    if (!rc && stat_source(src_text_path, &want_size, &want_mtime) == 0 &&
+        (have_size != want_size || have_mtime != want_mtime))
+        rc = FVH_ERR_STALE;          /* the text exists and is not the file this cache was parsed from */
+    if (!rc && n && fread(data, 4, n, fp) != n) rc = FVH_ERR_SHORT;
     fclose(fp);
     return rc;
 }
@@ -191,6 +249,7 @@ const char *fvh_strerror(int rc)
     case FVH_ERR_SHORT: return "file holds fewer values than requested";
     case FVH_ERR_FORMAT: return "bad format";
     case FVH_ERR_NOMEM: return "out of host memory";
+    case FVH_ERR_STALE: return "cache does not belong to the text file next to it";
     default: return "unknown fvh error";
     }
 }

@@ -28,6 +28,8 @@ def lib():
         L.fvh_read_ints_text.argtypes = [cp, vp, sz]
         L.fvh_write_bin.argtypes = [cp, vp, u32, u32, u32]
         L.fvh_read_bin.argtypes = [cp, vp, u32, u32, u32]
+        L.fvh_write_bin_src.argtypes = [cp, vp, u32, u32, u32, cp]
+        L.fvh_read_bin_src.argtypes = [cp, vp, u32, u32, u32, cp]
         L.fvh_strerror.restype = cp
         L.fvh_strerror.argtypes = [ci]
         _lib = L
@@ -108,6 +110,20 @@ def write_bin_i32(path, a):
 def read_bin_f32(path, rows, cols):
     out = np.empty((rows, cols), dtype=np.float32)
     _check(lib().fvh_read_bin(path.encode(), _ptr(out), 1, rows, cols), path)
+    return out
+
+
+def write_bin_f32_src(path, a, src_text_path):
+    """Cache bound to the text file it was parsed from (size + mtime in the header)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    a2 = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(1, -1)
+    _check(lib().fvh_write_bin_src(path.encode(), _ptr(a2), 1, a2.shape[0], a2.shape[1], src_text_path.encode()), path)
+
+
+def read_bin_f32_src(path, rows, cols, src_text_path):
+    """Raises IOError when the text file exists and is not the one the cache was made from."""
+    out = np.empty((rows, cols), dtype=np.float32)
+    _check(lib().fvh_read_bin_src(path.encode(), _ptr(out), 1, rows, cols, src_text_path.encode()), path)
     return out
 
 

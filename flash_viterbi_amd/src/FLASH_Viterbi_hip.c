@@ -48,10 +48,10 @@ static int load_f32(const char *kind, float *dst, unsigned rows, unsigned cols, 
     char txt[512], bin[512];
     input_name(txt, sizeof txt, kind, "txt");
     input_name(bin, sizeof bin, kind, "f32");
-    if (use_cache && fvh_read_bin(bin, dst, FVH_DTYPE_F32, rows, cols) == 0) return 0;
+    if (use_cache && fvh_read_bin_src(bin, dst, FVH_DTYPE_F32, rows, cols, txt) == 0) return 0;   /* stale or unbound: re-parse */
     int rc = fvh_read_floats_text(txt, dst, (size_t)rows * cols);
     if (rc) { fprintf(stderr, "%s: %s\n", txt, fvh_strerror(rc)); return rc; }
-    if (use_cache) (void)fvh_write_bin(bin, dst, FVH_DTYPE_F32, rows, cols);
+    if (use_cache) (void)fvh_write_bin_src(bin, dst, FVH_DTYPE_F32, rows, cols, txt);
     return 0;
 }
 
@@ -107,10 +107,15 @@ int main(void)
 
     fv_stats st;
     fv_last_stats(ctx, &st);
+    /* roofline fraction of the dominant kernel: 4 algorithmic bytes per trellis cell, K*K cells per
+     * step launch of the whole-sequence pass, against 8 TB/s; launch time = HIP-event time around those T-1
+     * back-to-back launches / (T-1) */
+    const double launch_s = T > 1 ? st.top_steps_ms * 1e-3 / (T - 1) : 0.0;
     fprintf(stderr, "score: %.9g\nmodel_upload_s: %.6f\ngpu_ms: %.4f\ncells: %lld\ncells_per_s: %.6g\n"
-                    "device_bytes: %lld\npasses: %d\nstep_launches: %lld\nkernel: %d\n",
+                    "device_bytes: %lld\npasses: %d\nstep_launches: %lld\nkernel: %d\nn_gpus: %d\nroofline_frac: %.4f\n",
             (double)score, st.set_model_ms * 1e-3, st.gpu_ms, st.cells,
-            (double)K * K * T / seconds_between(&t1, &t2), st.device_bytes, st.passes, st.step_launches, st.kernel);
+            (double)K * K * T / seconds_between(&t1, &t2), st.device_bytes, st.passes, st.step_launches, st.kernel,
+            st.ranks, launch_s > 0.0 ? 4.0 * K * K / launch_s / 8.0e12 : 0.0);
     fv_destroy(ctx);
     free(A); free(B); free(Pi); free(ob); free(path);
     return 0;

@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """run_hip.py — bench driver for the MI355X host programs; counterpart of the reference's
 src/run.py (same `parameters` / `file_names` lists, same config patching, same
-`time:` / `memory:` scraping, same CSV columns first) with three additions the
-reference lacks: the decoded path is kept and hashed, extra stderr statistics are
-recorded, and --check compares the path with a binary built from the reference's own
-source when /root/reference is present.
+`time:` / `memory:` scraping, same CSV columns first) with the additions SURVEY 8(f-2)
+asks for: the decoded path is kept and hashed, the GPU count, cells/s, the roofline
+fraction of the dominant kernel and further stderr statistics are recorded, and a
+path-equality flag against the reference program can be filled in from a file of
+expected path hashes (plain JSON; tools/ref_paths.py writes one by running binaries
+compiled from the reference's own sources — that checker lives outside this package).
 
-  python3 run_hip.py                 # every parameter set x every program
-  python3 run_hip.py --gen           # generate missing input files first (generate_data counterpart)
-  python3 run_hip.py --check         # also run the reference program and compare paths
+  python3 run_hip.py                      # every parameter set x every program
+  python3 run_hip.py --gen                # generate missing input files first (generate_data counterpart)
+  python3 run_hip.py --ref-md5 FILE.json  # fill ref_path_equal from {"<program>|K|M|T|prob|N|B": "<md5 of the path>"}
 """
 import csv
 import hashlib
+import json
 import os
 import re
 import subprocess
@@ -35,7 +38,8 @@ parameters = [
 ]
 SEED = 12          # generate_data -s
 CSV_HEADER = ["timestamp", "K_STATE", "T_STATE", "obserRouteLEN", "prob", "MAX_THREADS", "BeamSearchWidth",
-              "time", "memory", "path_md5", "cells_per_s", "gpu_ms", "model_upload_s", "device_bytes", "ref_path_equal"]
+              "time", "memory", "n_gpus", "cells_per_s", "roofline_frac", "path_md5", "ref_path_equal",
+              "gpu_ms", "model_upload_s", "device_bytes"]
 
 
 def patch_config(text, filename, p):
@@ -72,6 +76,8 @@ def run_c(filename, p):
     res = subprocess.run(fvbuild.program_cc(modified + ".c", modified), capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"compile ERROR: {res.stderr}")
+    # raw float32 caches next to the text files: safe by default because a cache is bound to the size and mtime
+    # of the text it was parsed from (include/flashvit_host.h, fvh_read_bin_src) and re-made when they differ
     env = dict(os.environ, FV_BIN_CACHE=os.environ.get("FV_BIN_CACHE", "1"))
     res = subprocess.run([modified], capture_output=True, text=True, env=env)
     if res.returncode != 0:
@@ -80,23 +86,21 @@ def run_c(filename, p):
     info = {"time": re.search(r"time: ([\d.]+)", out).group(1),            # reference run.py:75
             "memory": re.search(r"memory: (\d+)", out).group(1),            # reference run.py:76
             "path": re.search(r"path: \[([^\]]*)\]", out).group(1).split()}
-    for key in ("cells_per_s", "gpu_ms", "model_upload_s", "device_bytes"):
+    for key in ("cells_per_s", "gpu_ms", "model_upload_s", "device_bytes", "n_gpus", "roofline_frac"):
         m = re.search(rf"{key}: (\S+)", err)
         info[key] = m.group(1) if m else ""
     print(f"{filename} Time: {info['time']}, Memory: {info['memory']}")
     return info
 
 
-def reference_path(filename, p):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import build_ref
-    kind = "flashbs" if "BS" in filename else "flash"
-    try:
-        exe = build_ref.build(kind, p["K_STATE"], p["obserRouteLEN"], p["prob"], p["MAX_THREADS"],
-                              p["BeamSearchWidth"] if kind == "flashbs" else None, M=p["T_STATE"])
-    except FileNotFoundError:
-        return None
-    return [str(x) for x in build_ref.run(exe, data_path)["path"]]
+def ref_key(filename, p):
+    """Key of one (program, parameter set) in a --ref-md5 file."""
+    beam = p["BeamSearchWidth"] if "BS" in filename else 0
+    return "|".join(str(x) for x in (filename, p["K_STATE"], p["T_STATE"], p["obserRouteLEN"], p["prob"], p["MAX_THREADS"], beam))
+
+
+def path_md5(path_tokens):
+    return hashlib.md5((" ".join(str(x) for x in path_tokens)).encode()).hexdigest()
 
 
 def main():
@@ -104,7 +108,10 @@ def main():
     os.makedirs(data_path, exist_ok=True)
     fvbuild.build_host()
     fvbuild.build_hip()
-    check = "--check" in sys.argv
+    ref_md5 = {}
+    if "--ref-md5" in sys.argv:
+        with open(sys.argv[sys.argv.index("--ref-md5") + 1]) as fh:
+            ref_md5 = json.load(fh)
     for filename in file_names:
         csv_name = result_path + filename + "_result.csv"
         new = not os.path.exists(csv_name)
@@ -116,14 +123,13 @@ def main():
                 if "--gen" in sys.argv:
                     ensure_inputs(p)
                 info = run_c(filename, p)
-                same = ""
-                if check:
-                    ref = reference_path(filename, p)
-                    same = "" if ref is None else str(ref == info["path"])
+                md5 = path_md5(info["path"])
+                want = ref_md5.get(ref_key(filename, p))
+                same = "" if want is None else str(want == md5)
                 w.writerow([datetime.now().strftime("%Y-%m-%d %H:%M:%S"), p["K_STATE"], p["T_STATE"], p["obserRouteLEN"],
                             p["prob"], p.get("MAX_THREADS", "N/A"), p.get("BeamSearchWidth", "N/A"), info["time"],
-                            info["memory"], hashlib.md5((" ".join(info["path"])).encode()).hexdigest(),
-                            info["cells_per_s"], info["gpu_ms"], info["model_upload_s"], info["device_bytes"], same])
+                            info["memory"], info["n_gpus"], info["cells_per_s"], info["roofline_frac"], md5, same,
+                            info["gpu_ms"], info["model_upload_s"], info["device_bytes"]])
                 fh.flush()
 
 

@@ -25,6 +25,7 @@ enum {
     FVH_ERR_SHORT = -104,
     FVH_ERR_FORMAT = -105,
     FVH_ERR_NOMEM = -106,
+    FVH_ERR_STALE = -107,
 };
 
 enum { FVH_DTYPE_F32 = 1, FVH_DTYPE_I32 = 2 };
@@ -54,6 +55,17 @@ int fvh_read_ints_text(const char *path, int *out, size_t n);
 /* Raw cache of an already-parsed array: 16-byte header + little-endian payload. */
 int fvh_write_bin(const char *path, const void *data, uint32_t dtype, uint32_t rows, uint32_t cols);
 int fvh_read_bin(const char *path, void *data, uint32_t dtype, uint32_t rows, uint32_t cols);
+
+/* The same cache bound to the text file it was parsed from: the header ("FVB2") also holds that file's size
+ * and modification time.  fvh_read_bin_src refuses (FVH_ERR_STALE) a cache whose recorded source differs
+ * from the text file now at src_text_path — regenerated inputs keep their names (the names encode only K, T
+ * and prob, reference README.md:105-114), so a cache must never outlive its text; an unbound cache
+ * (fvh_write_bin, the generator's --bin output) is refused the same way whenever the text exists.  When
+ * src_text_path does not exist (cache-only data sets: K = 65536 has no text) any well-formed cache is taken. */
+int fvh_write_bin_src(const char *path, const void *data, uint32_t dtype, uint32_t rows, uint32_t cols,
+                      const char *src_text_path);
+int fvh_read_bin_src(const char *path, void *data, uint32_t dtype, uint32_t rows, uint32_t cols,
+                     const char *src_text_path);
 
 const char *fvh_strerror(int rc);
 

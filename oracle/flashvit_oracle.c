@@ -46,7 +46,8 @@ int fvo_set_threads(int n)
 struct fvo_model {
     int K, M;
     double *logA;   /* [K][K]  logA[k*K + i]  = log((double)A[k][i])          */
-    double *logAT;  /* [K][K]  logAT[i*K + k] = logA[k*K + i] (walk k contiguously) */
+    double *logAT;  /* [K][K]  logAT[i*K + k] = logA[k*K + i] (walk k contiguously); built by the first
+                       full-state decode (the beam variant never reads it: at K = 65536 it is 34 GB) */
     double *logB;   /* [K][M]  log((double)B[i][o])                            */
     double *logPi;  /* [K]                                                     */
 };
@@ -59,19 +60,33 @@ fvo_model *fvo_model_create(const float *A, const float *B, const float *Pi, int
     m->K = K; m->M = M;
     size_t kk = (size_t)K * K;
     m->logA = (double *)malloc(kk * sizeof(double));
-    m->logAT = (double *)malloc(kk * sizeof(double));
+    m->logAT = NULL;
     m->logB = (double *)malloc((size_t)K * M * sizeof(double));
     m->logPi = (double *)malloc((size_t)K * sizeof(double));
-    if (!m->logA || !m->logAT || !m->logB || !m->logPi) { fvo_model_destroy(m); return NULL; }
+    if (!m->logA || !m->logB || !m->logPi) { fvo_model_destroy(m); return NULL; }
+#pragma omp parallel for schedule(static)
     for (int k = 0; k < K; ++k)
-        for (int i = 0; i < K; ++i) {
-            double l = log((double)A[(size_t)k * K + i]);
-            m->logA[(size_t)k * K + i] = l;
-            m->logAT[(size_t)i * K + k] = l;
-        }
+        for (int i = 0; i < K; ++i)
+            m->logA[(size_t)k * K + i] = log((double)A[(size_t)k * K + i]);
     for (size_t x = 0; x < (size_t)K * M; ++x) m->logB[x] = log((double)B[x]);
     for (int i = 0; i < K; ++i) m->logPi[i] = log((double)Pi[i]);
     return m;
+}
+
+/* Column-major copy for the full-state cell (walks k contiguously); first use only. */
+static int model_need_logAT(fvo_model *m)
+{
+    if (m->logAT) return 0;
+    const int K = m->K;
+    double *t = (double *)malloc((size_t)K * K * sizeof(double));
+    if (!t) return FVO_ERR_NOMEM;
+    const int BLK = 64;
+#pragma omp parallel for schedule(static)
+    for (int i0 = 0; i0 < K; i0 += BLK)
+        for (int k = 0; k < K; ++k)
+            for (int i = i0; i < i0 + BLK && i < K; ++i) t[(size_t)i * K + k] = m->logA[(size_t)k * K + i];
+    m->logAT = t;
+    return 0;
 }
 
 void fvo_model_destroy(fvo_model *m)
@@ -240,6 +255,7 @@ int fvo_full_decode(const fvo_model *m, const int *ob, int T, int n_split,
      * miscounts its tasks and prints a wrong path.  Not restated. */
     if (n_split > 2 && T == 2 * n_split) return FVO_ERR_ARG;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= m->M) return FVO_ERR_ARG;
+    if (model_need_logAT((fvo_model *)m)) return FVO_ERR_NOMEM;
     const int K = m->K;
     int N = n_split;
     full_run r = { m, ob, T, path, 0, 0, 0.0f };
@@ -281,6 +297,7 @@ int fvo_full_forward(const fvo_model *m, const int *ob, int L, int R, int init_s
                      float *score_row, int *argtab)
 {
     if (!m || !ob || L < 0 || R < L || (init_state < 0 && L != 0)) return FVO_ERR_ARG;
+    if (model_need_logAT((fvo_model *)m)) return FVO_ERR_NOMEM;
     const int K = m->K;
     float *a = (float *)malloc(sizeof(float) * K), *b = (float *)malloc(sizeof(float) * K);
     if (!a || !b) { free(a); free(b); return FVO_ERR_NOMEM; }
@@ -309,6 +326,7 @@ int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, floa
 {
     if (!m || !ob || !path || T < 1) return FVO_ERR_ARG;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= m->M) return FVO_ERR_ARG;
+    if (model_need_logAT((fvo_model *)m)) return FVO_ERR_NOMEM;
     const int K = m->K, M = m->M;
     float *a = (float *)malloc(sizeof(float) * K), *b = (float *)malloc(sizeof(float) * K);
     int *T2 = (int *)malloc(sizeof(int) * (size_t)K * T);
@@ -381,6 +399,7 @@ int fvo_checkpoint_decode(const fvo_model *m, const int *ob, int T, int step, in
 {
     if (!m || !ob || !path || T < 1) return FVO_ERR_ARG;
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= m->M) return FVO_ERR_ARG;
+    if (model_need_logAT((fvo_model *)m)) return FVO_ERR_NOMEM;
     if (step <= 0) step = (int)floor(sqrt(1.0 * T));
     const int K = m->K;
     const int nck = (T + step - 1) / step;
@@ -524,6 +543,61 @@ static inline float beam_cell(const fvo_model *m, const hnode *h, int beam, int 
     return score;
 }
 
+/* beam_cell for a block of destinations [i0, i0+n), the heap slots in the OUTER loop: every destination
+ * still meets the slots in ascending order with strict '>' from (-FLT_MAX, -1) (FLASH_BS:439-446), so
+ * (score, arg) are those of beam_cell bit for bit; only the memory walk differs (the row of log A of a
+ * slot is read contiguously instead of one strided entry per cell), which is what makes K = 65536,
+ * B = 1024 (BASELINE configs[4]) finish in about a minute.  tests/test_oracle_golden.py runs every beam
+ * golden through this form and tests/test_oracle_blocked.py compares it with beam_cell cell by cell. */
+#define FVO_BLK 256
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+static void beam_block(const fvo_model *m, const hnode *h, int beam, int i0, int n, int o, float *scr, int *argv)
+{
+    const int K = m->K, M = m->M;
+    float tmp[FVO_BLK], sc[FVO_BLK];
+    int ar[FVO_BLK];
+    for (int i = 0; i < n; ++i) { tmp[i] = (float)m->logB[(size_t)(i0 + i) * M + o]; sc[i] = -FLT_MAX; ar[i] = -1; }
+    for (int k = 0; k < beam; ++k) {
+        const double *row = m->logA + (size_t)h[k + 1].state * K + i0;
+        const float v = h[k + 1].value;
+        for (int i = 0; i < n; ++i) {
+            const float s = tmp[i] + v;
+            const float ktmp = (float)((double)s + row[i]);
+            const int gt = ktmp > sc[i];
+            sc[i] = gt ? ktmp : sc[i];
+            ar[i] = gt ? k : ar[i];
+        }
+    }
+    memcpy(scr + i0, sc, sizeof(float) * (size_t)n);
+    memcpy(argv + i0, ar, sizeof(int) * (size_t)n);
+}
+
+/* All K destinations of one beam step (the parallel loop of both beam passes). */
+static void beam_step_all(const fvo_model *m, const hnode *h, int beam, int o, float *scr, int *argv)
+{
+    const int K = m->K;
+#pragma omp parallel for schedule(static)
+    for (int i0 = 0; i0 < K; i0 += FVO_BLK)
+        beam_block(m, h, beam, i0, K - i0 < FVO_BLK ? K - i0 : FVO_BLK, o, scr, argv);
+}
+
+/* Test hook: one step's scores and args by the cell-at-a-time form (blocked = 0) or the blocked form. */
+int fvo_beam_step_probe(const fvo_model *m, const float *hval, const int *hstate, int beam, int o, int blocked,
+                        float *scr, int *argv)
+{
+    if (!m || !hval || !hstate || beam < 1 || o < 0 || o >= m->M) return FVO_ERR_ARG;
+    hnode *h = (hnode *)malloc(sizeof(hnode) * ((size_t)beam + 1));
+    if (!h) return FVO_ERR_NOMEM;
+    heap_reset(h);
+    for (int k = 0; k < beam; ++k) { h[k + 1].value = hval[k]; h[k + 1].state = hstate[k]; h[k + 1].t3 = -1; }
+    if (blocked) beam_step_all(m, h, beam, o, scr, argv);
+    else for (int i = 0; i < m->K; ++i) scr[i] = beam_cell(m, h, beam, i, o, &argv[i]);
+    free(h);
+    return 0;
+}
+
 /* The whole-sequence end pick, FLASH_BS:456-461 / :376-381: slot 1, then slots
  * beam/2+2 .. beam; leaf slot beam/2+1 is never looked at. */
 static int beam_final_slot(const hnode *h, int beam, float *score_out)
@@ -559,8 +633,7 @@ static void beam_bisect(beam_run *r, int L, int R, int mid, hnode *H[2], float *
         const hnode *h = H[cur];
         hnode *n = H[cur ^ 1];
         heap_reset(n);
-#pragma omp parallel for schedule(static)
-        for (int i = 0; i < K; ++i) scr[i] = beam_cell(m, h, beam, i, o, &argv[i]);
+        beam_step_all(m, h, beam, o, scr, argv);
         const int carry = j > mid + 1;
         for (int i = 0; i < K; ++i) {       /* heap pushes stay in state order */
             int a = argv[i];
@@ -612,8 +685,7 @@ static int beam_ndivide(beam_run *r, int L, int R, int N, int *midpoint)
         while (p + 2 < N && j > midpoint[p + 1] + 1) ++p;
         for (int x = 0; x + 1 < N; ++x) heap_reset(H[cur ^ 1] + x * hs);
         const hnode *h1 = H[cur] + 1 * hs;          /* H[cur][1], as the reference reads it */
-#pragma omp parallel for schedule(static)
-        for (int i = 0; i < K; ++i) scr[i] = beam_cell(m, h1, beam, i, o, &argv[i]);
+        beam_step_all(m, h1, beam, o, scr, argv);
         for (int i = 0; i < K; ++i) {
             int a = argv[i];
             for (int x = 0; x <= p; ++x)

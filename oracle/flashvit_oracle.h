@@ -47,6 +47,11 @@ int fvo_full_decode(const fvo_model *m, const int *ob, int T, int n_split,
 int fvo_beam_decode(const fvo_model *m, const int *ob, int T, int n_split, int beam,
                     int *path, float *score, long long *cells);
 
+/* Test hook: scores and winning slots of one beam step over the slots (hval, hstate)[beam], by the
+ * cell-at-a-time restatement of FLASH_BS:437-446 (blocked = 0) or the row-streaming form the decoder uses. */
+int fvo_beam_step_probe(const fvo_model *m, const float *hval, const int *hstate, int beam, int o, int blocked,
+                        float *scr, int *argv);
+
 /* viterbi() of the reference's baseline Base_line/C implementations/vanilla Viterbi.c:125-173 (also the
  * output of its checkpoint Viterbi.c: same recurrence, different memory schedule). */
 int fvo_vanilla_decode(const fvo_model *m, const int *ob, int T, int *path, float *score);

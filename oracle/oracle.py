@@ -50,6 +50,7 @@ def lib():
         L.fvo_checkpoint_decode.argtypes = [vp, vp, ci, ci, vp, vp]
         L.fvo_checkpoint_memory_bytes.argtypes = [ci, ci, ci]
         L.fvo_checkpoint_memory_bytes.restype = ctypes.c_longlong
+        L.fvo_beam_step_probe.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp]
         L.fvo_set_threads.argtypes = [ci]
         L.fvo_full_memory_bytes.restype = ctypes.c_longlong
         L.fvo_full_memory_bytes.argtypes = [ci, ci, ci]
@@ -133,6 +134,17 @@ class OracleModel:
         if rc < 0 and check:
             raise OracleError(rc)
         return path, np.float32(score.value), rc
+
+    def beam_step_probe(self, hval, hstate, o, blocked):
+        """Scores and winning slots of one beam step; blocked=False is the cell-at-a-time restatement."""
+        hval = np.ascontiguousarray(hval, dtype=np.float32)
+        hstate = np.ascontiguousarray(hstate, dtype=np.int32)
+        scr = np.empty(self.K, dtype=np.float32)
+        arg = np.empty(self.K, dtype=np.int32)
+        rc = lib().fvo_beam_step_probe(self._h, _p(hval), _p(hstate), hval.size, int(o), 1 if blocked else 0, _p(scr), _p(arg))
+        if rc:
+            raise OracleError(rc)
+        return scr, arg
 
     def full_forward(self, ob, L, R, init_state=-1):
         ob = np.ascontiguousarray(ob, dtype=np.int32)

@@ -1,0 +1,106 @@
+"""GPU: BASELINE.json's large configurations at FULL size against the oracle, through the C ABI.
+
+  configs[2]  K=3965  T=4096           N=8   full-state FLASH      (tests/test_gpu_properties.py has the
+                                                                    size-independent properties of the same case)
+  configs[3]  K=16384 T=256  B=256     N=8   FLASH-BS
+  configs[4]  K=65536 T=1024 B=1024    N=8   FLASH-BS
+
+Bar: decoded path bit-exact, final score float32-equal, return code equal (a beam miss is part of the
+result).  The oracle (oracle/flashvit_oracle.c) is pinned to the reference's own binaries by
+tests/test_oracle_golden.py; at these sizes the reference programs themselves would need hours
+(single-threaded whole-sequence pass, one libm log() per cell), so the oracle is what runs here.
+Both beam step kernels are forced in turn (FV_OPT_DEBUG 256: float64 rows, 512: 16-bit filter + refine),
+then the library's own choice.
+
+cfg3 / cfg4 use the generate_data random stream (seed 12, as bench.py); cfg5 uses modelgen's
+"sparse_fast" builder — the same distributions from a vectorised random stream, because replaying
+generate_data's per-row K-element permutations takes minutes at K = 65536 (modelgen._sparse_fast32).
+"""
+import time
+
+import numpy as np
+import pytest
+
+import modelgen
+import oracle
+from flash_viterbi_amd import decoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _log(msg):
+    print(f"[baseline-configs] {msg}", flush=True)
+
+
+def _beam_case(spec, n_split, beam, partition_check=False):
+    t0 = time.time()
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    _log(f"K={spec['K']} model built in {time.time() - t0:.1f}s")
+    fv = decoder.FlashViterbi(0)
+    try:
+        t0 = time.time()
+        fv.set_model(A, Bm, Pi)
+        _log(f"fv_set_model {time.time() - t0:.1f}s")
+        got = {}
+        for dbg in (256, 512, 0):
+            fv.set_option(decoder.OPT_DEBUG, dbg)
+            path, score, rc = fv.decode_beam(ob, n_split, beam, decoder.MODE_REFERENCE)
+            st = fv.stats()
+            got[dbg] = (path, score, rc)
+            _log(f"FV_OPT_DEBUG={dbg}: gpu_ms {st['gpu_ms']:.2f} exact replays {st['beam_exact_sets']} rc {rc}")
+        fv.set_option(decoder.OPT_DEBUG, 0)
+        if partition_check:
+            # a 1-GPU run with n_split = 8 must equal the 8-rank run; every simulated rank decodes
+            # its share on this GPU and the product's merge puts the slices together
+            slices = []
+            for r in range(8):
+                fv.set_partition(r, 8)
+                slices.append(fv.decode_beam(ob, n_split, beam)[0])
+            fv.set_partition(0, 1)
+            merged = decoder.merge_paths(ob.size, n_split, 8, np.stack(slices))
+            assert merged.tolist() == got[0][0].tolist(), "8-rank partition differs from the 1-rank decode"
+    finally:
+        fv.close()
+    t0 = time.time()
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, n_split, beam)
+    om.close()
+    _log(f"oracle {time.time() - t0:.1f}s score {oscore} rc {orc}")
+    for dbg, (path, score, rc) in got.items():
+        assert path.tolist() == opath.tolist(), f"FV_OPT_DEBUG={dbg}: path differs from the oracle"
+        assert score == oscore and rc == orc, f"FV_OPT_DEBUG={dbg}: score/rc {score}/{rc} vs {oscore}/{orc}"
+
+
+def test_cfg3_full_decode_equals_oracle():
+    """BASELINE configs[2] on one GPU: K=3965, T=4096, n_split=8, FV_MODE_REFERENCE, dense and sparse kernels."""
+    spec = dict(kind="data_script", K=3965, M=50, T=4096, prob=0.112, seed=12)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    fv = decoder.FlashViterbi(0)
+    try:
+        fv.set_model(A, Bm, Pi)
+        got = {}
+        for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_AUTO):
+            fv.set_option(decoder.OPT_KERNEL, kernel)
+            got[kernel] = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
+            _log(f"cfg3 kernel {fv.stats()['kernel']}: gpu_ms {fv.stats()['gpu_ms']:.1f}")
+    finally:
+        fv.close()
+    t0 = time.time()
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.full_decode(ob, 8)
+    om.close()
+    _log(f"cfg3 oracle {time.time() - t0:.1f}s")
+    assert orc == 0
+    for kernel, (path, score, rc) in got.items():
+        assert rc == 0 and path.tolist() == opath.tolist() and score == oscore, kernel
+
+
+def test_cfg4_beam_decode_equals_oracle():
+    """BASELINE configs[3]: K=16384, T=256, B=256, n_split=8 (127 passes, batched launches, in-kernel replays)."""
+    _beam_case(dict(kind="data_script", K=16384, M=50, T=256, prob=0.112, seed=12), 8, 256, partition_check=True)
+
+
+def test_cfg5_beam_decode_equals_oracle():
+    """BASELINE configs[4]: K=65536, T=1024, B=1024, n_split=8 (the select's 64-round instantiation at its K
+    limit, ~1500 exact replays, 34 GB float64 row table), plus the 8-rank partition of SURVEY 8(e)."""
+    _beam_case(dict(kind="sparse_fast", K=65536, M=50, T=1024, prob=0.112, seed=12), 8, 1024, partition_check=True)

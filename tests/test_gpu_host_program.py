@@ -53,6 +53,47 @@ def test_host_program_prints_reference_path(tmp_path, name, case, algo):
             assert float(re.search(r"score: (\S+)", out.stderr).group(1)) == pytest.approx(r["score"], rel=1e-7)
 
 
+def test_run_hip_main_writes_reference_schema_plus_gpu_columns(tmp_path, monkeypatch):
+    """run_hip.main() end to end on a small parameter set: the CSV keeps the reference's columns first
+    (src/run.py:105) and adds n_gpus, cells/s, roofline fraction, the path hash and the path-equality flag
+    (SURVEY 8 f-2), the flag filled from a --ref-md5 file holding the golden path of the reference binary."""
+    import csv
+    import json
+    import sys
+    run_hip = _run_hip_module()
+    g = next(x for x in load_goldens() if x["name"] == "cfg1_K128_T256")
+    spec = g["spec"]
+    rf = next(x for x in g["runs"] if x["algo"] == "flash" and x["N"] == 8)
+    rb = next(x for x in g["runs"] if x["algo"] == "flashbs" and x["N"] == 8 and x["B"] == 32)
+    data_dir, res_dir, src_dir = str(tmp_path / "data") + os.sep, str(tmp_path / "result") + os.sep, str(tmp_path / "src") + os.sep
+    os.makedirs(src_dir)
+    for name in run_hip.file_names:
+        with open(os.path.join(ROOT, "flash_viterbi_amd", "src", name + ".c")) as f:
+            open(src_dir + name + ".c", "w").write(f.read())
+    modelgen.write_text(spec, data_dir)
+    p = {"K_STATE": spec["K"], "T_STATE": spec["M"], "obserRouteLEN": spec["T"], "prob": spec["prob"], "MAX_THREADS": 8, "BeamSearchWidth": 32}
+    monkeypatch.setattr(run_hip, "data_path", data_dir)
+    monkeypatch.setattr(run_hip, "result_path", res_dir)
+    monkeypatch.setattr(run_hip, "base_path", src_dir)
+    monkeypatch.setattr(run_hip, "parameters", [p])
+    ref = {run_hip.ref_key("FLASH_Viterbi_hip", p): run_hip.path_md5(rf["path"]),
+           run_hip.ref_key("FLASH_BS_Viterbi_hip", p): run_hip.path_md5(rb["path"])}
+    ref_file = tmp_path / "ref.json"
+    ref_file.write_text(json.dumps(ref))
+    monkeypatch.setattr(sys, "argv", ["run_hip.py", "--ref-md5", str(ref_file)])
+    run_hip.main()
+    run_hip.main()                       # second run: appends, reads the bound .f32 caches
+    for name, r in (("FLASH_Viterbi_hip", rf), ("FLASH_BS_Viterbi_hip", rb)):
+        rows = list(csv.reader(open(res_dir + name + "_result.csv")))
+        assert rows[0][:9] == ["timestamp", "K_STATE", "T_STATE", "obserRouteLEN", "prob", "MAX_THREADS", "BeamSearchWidth", "time", "memory"]
+        assert len(rows) == 3
+        for row in rows[1:]:
+            d = dict(zip(rows[0], row))
+            assert int(d["memory"]) == r["memory"] and d["n_gpus"] == "1" and d["ref_path_equal"] == "True"
+            assert float(d["cells_per_s"]) > 0 and 0.0 < float(d["roofline_frac"]) < 1.5
+            assert d["path_md5"] == run_hip.path_md5(r["path"])
+
+
 def test_host_program_reports_missing_input(tmp_path):
     run_hip = _run_hip_module()
     src = open(os.path.join(ROOT, "flash_viterbi_amd", "src", "FLASH_Viterbi_hip.c")).read()

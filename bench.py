@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — FLASH Viterbi decode throughput on MI355X.
+"""bench.py — FLASH / FLASH-BS Viterbi decode throughput on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete decode of the BASELINE workload (configs[1]): K=3965 states,
-T=256 observations, M=50 symbols, generate_data model (-s 12 -p 0.112), n_split=8, in
-FV_MODE_REFERENCE (the reference's divide-and-conquer task tree replayed pass for pass,
-bit-exact by construction), model tables already resident in HBM (fv_set_model is outside the
-timed region; the 1 KB observation upload and 1 KB path download are inside it).
+One "step" = one complete decode of the workload, model tables already resident in HBM (fv_set_model is
+outside the timed region; the observation upload and the path download, a few KB, are inside it).
 
-metric = trellis cells/s with cells = K*K*T per decode (BASELINE.json's K·K·T ops).
+  cfg2 (default)  BASELINE configs[1]: full-state FLASH, K=3965 T=256 M=50 prob=0.112 seed=12 n_split=8,
+                  FV_MODE_REFERENCE (the reference's divide-and-conquer task tree replayed pass for pass)
+  cfg3            configs[2]: the same model, T=4096 (the N>1 case north_star names)
+  cfg4            configs[3]: FLASH-BS K=16384 T=256 beam=256 n_split=8
+  cfg5            configs[4]: FLASH-BS K=65536 T=1024 beam=1024 n_split=8
 
-N > 1: the n_split top-level segments are dealt round-robin to ranks (one process per GPU),
-every rank runs the whole-sequence pass, one RCCL all-gather merges the path slices
-(include/flashvit.h, fv_comm_init).  Same total work for every N => "scaling": "strong".
-The whole-sequence pass is serial in T, so the curve is Amdahl-bound (Multi-GPU).
+metric = trellis cells/s with cells = K*K*T per decode (BASELINE.json's K·K·T ops); for the FLASH-BS
+workloads the same JSON line carries K*beam*T cells (report K·B·(T-1) and say so) in
+config.cells_per_decode.
+
+N > 1: the n_split top-level segments are dealt round-robin to ranks (one process per GPU), every rank
+runs the whole-sequence pass, one RCCL all-gather merges the path slices (include/flashvit.h,
+fv_comm_init).  Same total work for every N => "scaling": "strong".  The whole-sequence pass is serial in
+T, so the curve is Amdahl-bound (Multi-GPU).
+
+cpu_baseline (rank 0, N = 1 only): SURVEY 8(d)'s protocol for the bench configuration — the reference
+program itself (oracle/_ref, built from the reference's sources with run.py:54's flags), MAX_THREADS =
+n_split, on the FULL cfg2 sequence, 1 warm + 3 timed runs of its own `time:` line, median; plus one
+MAX_THREADS=1 run on a T=16 sample.  `cores` = physical cores of this host, `threads` = what the program
+used.  cfg3 uses a T=64 sample of the reference program; cfg4/cfg5 the oracle port (their text inputs
+would be 5 / 82 GB for the reference's fscanf loader).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,6 +36,7 @@ import argparse
 import json
 import os
 import shutil
+import statistics
 import sys
 import tempfile
 import time
@@ -36,59 +49,162 @@ import numpy as np  # noqa: E402
 from flash_viterbi_amd import decoder, hostio  # noqa: E402
 from flash_viterbi_amd.generate_data import data_script  # noqa: E402
 
-K, M, T, PROB, SEED, N_SPLIT = 3965, 50, 256, 0.112, 12, 8
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-CPU_SAMPLE_T = 64            # bounded CPU-baseline sample: first 64 observations of the same workload
-CPU_THREADS = 8
+M_SYMBOLS, PROB, SEED, N_SPLIT = 50, 0.112, 12, 8
+
+WORKLOADS = {
+    "cfg2": dict(kind="full", K=3965, T=256, beam=0, gen="data_script", steps=20, warmup=3, label="BASELINE configs[1]"),
+    "cfg3": dict(kind="full", K=3965, T=4096, beam=0, gen="data_script", steps=5, warmup=1, label="BASELINE configs[2]"),
+    "cfg4": dict(kind="beam", K=16384, T=256, beam=256, gen="data_script", steps=10, warmup=2, label="BASELINE configs[3]"),
+    "cfg5": dict(kind="beam", K=65536, T=1024, beam=1024, gen="fast", steps=3, warmup=1, label="BASELINE configs[4]"),
+}
+KERNEL_NAMES = {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>",
+                3: "fvk::trellis_step<fvk::half_t,1,16,false>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>",
+                5: "fvk::trellis_step_sparse<1>"}
 
 
-def build_workload():
-    A64, B64, Pi64 = data_script.make_model64(K, M, SEED, PROB)
-    A, B, Pi = hostio.quantize_text16(A64), hostio.quantize_text16(B64), hostio.quantize_text16(Pi64)
-    ob = np.asarray(data_script.make_observations(T, M, SEED), dtype=np.int32)
-    return (A64, B64, Pi64), (A, B, Pi), ob
+def build_workload(w):
+    """(model64 or None, (A, B, Pi) float32 as the reference loader reads them, observations)."""
+    K, T = w["K"], w["T"]
+    ob = np.asarray(data_script.make_observations(T, M_SYMBOLS, SEED), dtype=np.int32)
+    if w["gen"] == "fast":       # K = 65536: generate_data's own random stream takes minutes to replay (see its docstring)
+        return None, data_script.make_model32_fast(K, M_SYMBOLS, SEED, PROB), ob
+    A64, B64, Pi64 = data_script.make_model64(K, M_SYMBOLS, SEED, PROB)
+    return (A64, B64, Pi64), (hostio.quantize_text16(A64), hostio.quantize_text16(B64), hostio.quantize_text16(Pi64)), ob
 
 
-def cpu_baseline(model64, ob, hip_path_sample):
-    """Reference pthread program (compiled from the reference's own sources into oracle/_ref by
-    oracle/build_ref.py) on a bounded sample; falls back to the oracle port if the binary is absent."""
+def host_cores():
+    """(physical cores of the machine, CPUs this process may run on)."""
+    phys = set()
+    try:
+        pkg = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pkg = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        phys.add((pkg, core))
+                    pkg = core = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return (len(phys) or (os.cpu_count() or 1)), usable
+
+
+def run_reference(kind, K, T, N, beam, model64, ob, runs, warm):
+    """The reference program (oracle/_ref) on the first T observations: list of its `time:` values and its path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import build_ref
+    exe = build_ref.build(kind, K, T, PROB, N, beam if kind == "flashbs" else None)     # FileNotFoundError if not prebuilt
     A64, B64, Pi64 = model64
-    sample = f"K={K} T={CPU_SAMPLE_T} (first {CPU_SAMPLE_T} observations of the bench workload), MAX_THREADS={CPU_THREADS}"
+    tmp = tempfile.mkdtemp(prefix="fvbench_")
+    times, path = [], None
     try:
-        exe = build_ref.build("flash", K, CPU_SAMPLE_T, PROB, CPU_THREADS)
-    except FileNotFoundError:
-        exe = None
-    if exe:
-        tmp = tempfile.mkdtemp(prefix="fvbench_")
-        try:
-            data_script.write_files(tmp, K, CPU_SAMPLE_T, PROB, A64, B64, Pi64, ob[:CPU_SAMPLE_T], text=True)
+        data_script.write_files(tmp, K, T, PROB, A64, B64, Pi64, ob[:T], text=True)
+        for r in range(warm + runs):
             out = build_ref.run(exe, tmp, timeout=1200)
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
-        return {"value": K * K * CPU_SAMPLE_T / out["time"], "unit": "cells/s", "cores": CPU_THREADS,
-                "kind": "reference", "seconds": out["time"],
-                "sample": sample + "; reference src/FLASH_Viterbi_multithread.c built with run.py:54 flags, its own `time:` line",
-                "path_equal_to_hip": bool(out["path"] == hip_path_sample)}
+            path = out["path"]
+            if r >= warm:
+                times.append(out["time"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return times, path
+
+
+def cpu_baseline_full(w, model64, ob, fv):
+    """SURVEY 8(d) CPU baseline for the full-state workloads (reference binary, see the module docstring)."""
+    K, T = w["K"], w["T"]
+    phys, usable = host_cores()
+    full = w["T"] <= 256                      # cfg2: the bench configuration itself; cfg3: a T=64 sample
+    Ts = T if full else 64
+    hip_sample, _, _ = fv.decode_full(ob[:Ts], N_SPLIT, decoder.MODE_REFERENCE)
+    try:
+        times, path = run_reference("flash", K, Ts, N_SPLIT, 0, model64, ob, runs=3 if full else 1, warm=1 if full else 0)
+    except FileNotFoundError:
+        return cpu_baseline_port(w, model64, ob, fv, None)
+    med = statistics.median(times)
+    out = {"value": K * K * Ts / med, "unit": "cells/s", "cores": phys, "threads": N_SPLIT, "usable_cpus": usable,
+           "kind": "reference", "seconds": med, "runs": times, "protocol": "1 warm + 3 timed, median" if full else "1 run",
+           "sample": (f"K={K} T={Ts}" + (" (the full bench sequence)" if full else f" (first {Ts} observations of the bench workload)") +
+                      f", MAX_THREADS={N_SPLIT}; reference src/FLASH_Viterbi_multithread.c built with run.py:54 flags, its own `time:` line"),
+           "path_equal_to_hip": bool(path == hip_sample.tolist())}
+    if full:
+        T1 = 16
+        try:
+            t1, p1 = run_reference("flash", K, T1, 1, 0, model64, ob, runs=1, warm=0)
+            h1, _, _ = fv.decode_full(ob[:T1], 1, decoder.MODE_REFERENCE)
+            out["single_thread"] = {"value": K * K * T1 / t1[0], "unit": "cells/s", "threads": 1, "seconds": t1[0],
+                                    "sample": f"K={K} T={T1} (first {T1} observations), MAX_THREADS=1",
+                                    "path_equal_to_hip": bool(p1 == h1.tolist())}
+        except FileNotFoundError:
+            pass
+    return out
+
+
+def cpu_baseline_port(w, model64, ob, fv, f32):
+    """The oracle port (OpenMP) on a bounded sample: used where the reference binary is not practical."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    oracle.set_threads(CPU_THREADS)
-    om = oracle.OracleModel(hostio.quantize_text16(A64), hostio.quantize_text16(B64), hostio.quantize_text16(Pi64))
+    K, T, beam = w["K"], w["T"], w["beam"]
+    phys, usable = host_cores()
+    threads = oracle.set_threads(min(usable, 16))
+    if f32 is None:
+        f32 = tuple(hostio.quantize_text16(x) for x in model64)
+    Ts = min(T, 256 if K <= 16384 else 64)
+    om = oracle.OracleModel(*f32)
     t0 = time.time()
-    path, _, _, _ = om.full_decode(ob[:CPU_SAMPLE_T], CPU_THREADS)
+    if w["kind"] == "beam":
+        path, _, _, _ = om.beam_decode(ob[:Ts], N_SPLIT, beam)
+        hip, _, _ = fv.decode_beam(ob[:Ts], N_SPLIT, beam, decoder.MODE_REFERENCE)
+    else:
+        path, _, _, _ = om.full_decode(ob[:Ts], N_SPLIT)
+        hip, _, _ = fv.decode_full(ob[:Ts], N_SPLIT, decoder.MODE_REFERENCE)
     dt = time.time() - t0
-    return {"value": K * K * CPU_SAMPLE_T / dt, "unit": "cells/s", "cores": CPU_THREADS, "kind": "port",
-            "seconds": dt, "sample": sample + "; oracle/flashvit_oracle.c (OpenMP), log tables precomputed",
-            "path_equal_to_hip": bool(path.tolist() == hip_path_sample)}
+    om.close()
+    return {"value": K * K * Ts / dt, "unit": "cells/s", "cores": phys, "threads": threads, "usable_cpus": usable, "kind": "port",
+            "seconds": dt, "protocol": "1 run",
+            "sample": f"K={K} T={Ts} (first {Ts} observations) n_split={N_SPLIT}" + (f" beam={beam}" if beam else "") +
+                      "; oracle/flashvit_oracle.c (OpenMP), log tables precomputed"
+                      + ("; the reference program's text inputs would be 5 GB (K=16384) / 82 GB (K=65536) for its fscanf loader" if K > 4096 else ""),
+            "beam_cells_per_sec": (K * beam * Ts / dt) if beam else None,
+            "path_equal_to_hip": bool(path.tolist() == hip.tolist())}
+
+
+def load_traffic(kernel_name):
+    """PMC-measured HBM bytes per launch of `kernel_name` from the committed profile summary, with its provenance."""
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.isfile(tr_file):
+        return None, None
+    with open(tr_file) as f:
+        trj = json.load(f)
+    ent = trj.get("by_kernel", {}).get(kernel_name)
+    if not ent:
+        return None, None
+    src = f"profiles/traffic.json ({trj.get('source', 'rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes')}; {trj.get('date', 'round 1')}); NOT measured by this run"
+    return ent.get("hbm_bytes_per_launch"), src
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    w = WORKLOADS[args.workload]
+    if args.steps is None:
+        args.steps = w["steps"]
+    if args.warmup is None:
+        args.warmup = w["warmup"]
+    K, T, beam = w["K"], w["T"], w["beam"]
+    is_beam = w["kind"] == "beam"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +214,7 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    model64, (A, B, Pi), ob = build_workload()
+    model64, (A, B, Pi), ob = build_workload(w)
     gather_mode = "ncclAllGather inside libflashvit"
     dist = None
     if "RANK" in os.environ:      # launched by torch.distributed.run (also exercised with 1 rank)
@@ -106,16 +222,22 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    fv = decoder.FlashViterbi(local_rank)
-    fv.set_model(A, B, Pi)
-    # The timed region runs the DENSE streaming kernel (every one of the K*K cells of every step is read
-    # and evaluated: that is what "K*K*T cells" counts).  The library's AUTO choice for this model is the
-    # sparse walk (non-zero transitions only, same bits out); it is measured afterwards and reported as
-    # `sparse_walk`, never as `value`.
-    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+
+    def new_decoder():
+        d = decoder.FlashViterbi(local_rank)
+        d.set_model(A, B, Pi)
+        # full-state workloads: the timed region runs the DENSE streaming kernel (every one of the K*K cells of
+        # every step is read and evaluated: that is what "K*K*T cells" counts).  The library's AUTO choice for
+        # this model is the sparse walk (non-zero transitions only, same bits out); it is measured afterwards
+        # and reported as `sparse_walk`, never as `value`.
+        if not is_beam:
+            d.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+        return d
+
+    fv = new_decoder()
     if dist is not None:
-        # torch.distributed is the rendezvous only: the 128-byte RCCL id travels over it, the
-        # data-path collective (one all-gather per decode) is issued by libflashvit on its own stream
+        # torch.distributed is the rendezvous only: the 128-byte RCCL id travels over it, the data-path
+        # collective (one all-gather per decode) is issued by libflashvit on its own stream
         uid = [decoder.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ok = torch.ones(1, device="cuda")
@@ -128,9 +250,7 @@ def main():
         if ok.item() == 0:
             if fv._h:
                 fv.close()
-            fv = decoder.FlashViterbi(local_rank)
-            fv.set_model(A, B, Pi)
-            fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+            fv = new_decoder()
             fv.set_partition(rank, world)
             gather_mode = "torch.distributed.all_gather + fv_merge_paths"
 
@@ -141,7 +261,11 @@ def main():
             torch.cuda.synchronize()
 
     def decode():
-        path, score, rc = fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE)   # synchronous: returns after its stream drained
+        # synchronous: returns after the library's stream has drained
+        if is_beam:
+            path, score, rc = fv.decode_beam(ob, N_SPLIT, beam, decoder.MODE_REFERENCE)
+        else:
+            path, score, rc = fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE)
         if dist is not None and gather_mode.startswith("torch"):
             import torch
             mine = torch.from_numpy(path).cuda()
@@ -159,7 +283,7 @@ def main():
         path, score, rc = decode()
         s_ = fv.stats()
         top_ms += s_["top_pass_ms"]
-        steps_ms += s_["top_steps_ms"]      # HIP events (library's stream) around the T-1 step launches of the whole-sequence pass
+        steps_ms += s_["top_steps_ms"]      # HIP events on the library's stream around the T-1 steps of the whole-sequence pass
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -169,76 +293,85 @@ def main():
         dt = float(tmax.item())
     st = fv.stats()
 
-    # roofline of the dominant kernel (trellis_step with 1 task per launch = the whole-sequence pass):
-    # average launch duration = HIP-event time around its T-1 back-to-back launches in the TIMED region
-    # divided by T-1, i.e. kernel time plus the dispatch gap to the next launch (rocprofv3's per-kernel
-    # average, profiles/, excludes part of that gap and reads ~8 % lower).
+    # Roofline of the dominant kernel: the step of the whole-sequence pass (T-1 dependent steps per decode).
+    #   full-state: one trellis_step launch per step, 4*K*K algorithmic bytes (4 B per trellis cell);
+    #   FLASH-BS:   beam_step + top-B select per step, 4*B*K algorithmic bytes (4 B per (beam entry, destination) cell).
+    # Step time = HIP-event time around those T-1 back-to-back steps in the TIMED region / (T-1), i.e. kernel time plus
+    # the dispatch gap to the next launch (rocprofv3's per-kernel average, profiles/, excludes part of that gap).
     launch_us = 1e3 * (steps_ms / args.steps) / (T - 1)
-    alg_bytes_per_launch = 4.0 * K * K                      # 4 B per trellis cell, K*K cells per step
-    achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
-    ps_ = fv.decode_full(ob, N_SPLIT, decoder.MODE_SINGLE_PASS)
-    ps = fv.stats()
-    # extra: the library's AUTO kernel for this model (sparse walk over the non-zero transitions)
-    sparse = None
-    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
-    for _ in range(2):
-        decode()
-    a_ = fv.stats()
-    if a_["kernel"] == decoder.KERNEL_SPARSE_Q16:
-        nd = max(3, args.steps // 4)
-        barrier()
-        t1 = time.perf_counter()
-        ssteps = 0.0
-        for _ in range(nd):
+    alg_bytes = 4.0 * K * (beam if is_beam else K)
+    achieved = alg_bytes / (launch_us * 1e-6) / 1e9
+    kname = "fvb::beam_step(+_q16) + fvb::topb_select" if is_beam else KERNEL_NAMES[st["kernel"]]
+    traffic, traffic_src = (None, None) if is_beam else load_traffic(kname)
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "achieved_is": "ALGORITHMIC GB/s (4 B per cell / step time): the SURVEY 8(d) fraction, not bytes moved",
+                "traffic": traffic, "traffic_source": traffic_src,
+                "physical_gbs": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
+                "physical_frac": (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "kernel": kname, "launch_us": launch_us, "alg_bytes_per_launch": alg_bytes, "launches_per_decode": T - 1,
+                "table_bytes_streamed_per_launch": st["table_bytes_per_step"]}
+
+    extra = {}
+    if not is_beam:
+        fv.decode_full(ob, N_SPLIT, decoder.MODE_SINGLE_PASS)
+        extra["single_pass_mode_ms"] = fv.stats()["gpu_ms"]
+        # the library's AUTO kernel for this model (sparse walk over the non-zero transitions)
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+        for _ in range(2):
             decode()
-            ssteps += fv.stats()["top_steps_ms"]
-        barrier()
-        sw = time.perf_counter() - t1
-        sparse = {"kernel": "fvk::trellis_step_sparse<1>", "transition_density": a_["density"],
-                  "decode_ms": 1e3 * sw / nd, "cells_per_sec_dense_equivalent": K * K * T * nd / sw,
-                  "launch_us": 1e3 * (ssteps / nd) / (T - 1), "stored_bytes_per_launch": a_["table_bytes_per_step"],
-                  "note": "only the non-zero transitions are stored and visited (log 0 = -inf can never win, "
-                          "reference FLASH_Viterbi_multithread.c:171): bit-identical output, fewer cells evaluated; "
-                          "not comparable with the HBM roofline of the K*K sweep"}
-    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
-    traffic = None
-    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-    kname = {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>",
-             3: "fvk::trellis_step<fvk::half_t,1,16,false>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>",
-             5: "fvk::trellis_step_sparse<1>"}[st["kernel"]]
-    if os.path.isfile(tr_file):
-        with open(tr_file) as f:
-            trj = json.load(f)
-        traffic = trj.get("by_kernel", {}).get(kname, {}).get("hbm_bytes_per_launch")
+        a_ = fv.stats()
+        if a_["kernel"] == decoder.KERNEL_SPARSE_Q16:
+            nd = max(3, args.steps // 4)
+            barrier()
+            t1 = time.perf_counter()
+            ssteps = 0.0
+            for _ in range(nd):
+                decode()
+                ssteps += fv.stats()["top_steps_ms"]
+            barrier()
+            sw = time.perf_counter() - t1
+            extra["sparse_walk"] = {
+                "kernel": "fvk::trellis_step_sparse<1>", "transition_density": a_["density"],
+                "decode_ms": 1e3 * sw / nd, "cells_per_sec_dense_equivalent": K * K * T * nd / sw,
+                "launch_us": 1e3 * (ssteps / nd) / (T - 1), "stored_bytes_per_launch": a_["table_bytes_per_step"],
+                "note": "only the non-zero transitions are stored and visited (log 0 = -inf can never win, "
+                        "reference FLASH_Viterbi_multithread.c:171): bit-identical output, fewer cells evaluated; "
+                        "not comparable with the HBM roofline of the K*K sweep"}
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
 
     if rank == 0:
+        cells = K * K * T
         line = {
-            "metric": "trellis_cells_per_sec", "value": K * K * T * args.steps / dt, "unit": "cells/s",
+            "metric": "trellis_cells_per_sec", "value": cells * args.steps / dt, "unit": "cells/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 scores (+f64 add per cell, rounded to f32 as the reference does)",
             "data": "synthetic",
-            "config": {"workload": f"FLASH Viterbi full-state decode K={K} T={T} M={M} prob={PROB} seed={SEED} "
-                                   f"n_split={N_SPLIT} mode=reference (BASELINE configs[1])",
-                       "kernel": {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16"}[st["kernel"]],
-                       "kernel_note": "dense K*K sweep forced for value/roofline; the library's AUTO choice for this "
-                                      "model is the sparse walk, reported separately as sparse_walk",
-                       "transition_density": st["density"],
+            "config": {"workload": (f"FLASH-BS dynamic-beam decode K={K} T={T} M={M_SYMBOLS} beam={beam} prob={PROB} seed={SEED} n_split={N_SPLIT} mode=reference ({w['label']})"
+                                    if is_beam else
+                                    f"FLASH Viterbi full-state decode K={K} T={T} M={M_SYMBOLS} prob={PROB} seed={SEED} n_split={N_SPLIT} mode=reference ({w['label']})"),
+                       "cells_per_decode": cells,
+                       "beam_cells_per_decode": K * beam * T if is_beam else None,
+                       "beam_cells_per_sec": (K * beam * T * args.steps / dt) if is_beam else None,
+                       "model_generator": "generate_data random stream (data_script.py -s 12)" if w["gen"] == "data_script"
+                                          else "data_script.make_model32_fast (same distributions, vectorised random stream)",
+                       "kernel": ("beam_step / beam_step_q16 by launch size" if is_beam else
+                                  {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16"}[st["kernel"]]),
+                       "kernel_note": (None if is_beam else "dense K*K sweep forced for value/roofline; the library's AUTO choice for this "
+                                       "model is the sparse walk, reported separately as sparse_walk"),
+                       "transition_density": st["density"] if not is_beam else None,
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
-                       "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none"},
+                       "exact_heap_replays_on_critical_path": st["beam_exact_sets"] if is_beam else None,
+                       "rc": int(rc),
+                       "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none",
+                       "multi_gpu_status": "RCCL all-gather path unverified on hardware until a driver SCALE run exists" if args.gpus == 1 else None},
             "decode_ms": 1e3 * dt / args.steps,
             "forward_pass_ms": top_ms / args.steps,
-            "forward_pass_cells_per_sec": K * K * (T - 1) / (1e-3 * top_ms / args.steps),
-            "single_pass_mode_ms": ps["gpu_ms"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname, "launch_us": launch_us,
-                         "alg_bytes_per_launch": alg_bytes_per_launch, "launches_per_decode": T - 1,
-                         "table_bytes_streamed_per_launch": ps["table_bytes_per_step"]},
+            "forward_pass_cells_per_sec": K * (beam if is_beam else K) * (T - 1) / (1e-3 * top_ms / args.steps),
+            "roofline": roofline,
         }
-        if sparse is not None:
-            line["sparse_walk"] = sparse
-        if args.gpus == 1:
+        line.update(extra)
+        if args.gpus == 1 and args.workload == "cfg2":
             # extra: the FLASH-BS variant on the same model (never part of `value`)
             BEAM = 256
             fv.decode_beam(ob, N_SPLIT, BEAM)
@@ -252,8 +385,10 @@ def main():
                                 "beam_cells_per_sec": K * BEAM * T / bdt, "exact_heap_replays_on_critical_path": bst["beam_exact_sets"],
                                 "rc": int(brc)}
         if args.gpus == 1 and not args.no_cpu_baseline:
-            hip_sample, _, _ = fv.decode_full(ob[:CPU_SAMPLE_T], CPU_THREADS, decoder.MODE_REFERENCE)
-            line["cpu_baseline"] = cpu_baseline(model64, ob, hip_sample.tolist())
+            if is_beam or model64 is None:
+                line["cpu_baseline"] = cpu_baseline_port(w, model64, ob, fv, (A, B, Pi))
+            else:
+                line["cpu_baseline"] = cpu_baseline_full(w, model64, ob, fv)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -483,6 +483,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.beam_exact_sets = (long long)counters[2];
     st.beam_dup_cols = (long long)counters[3];
     st.beam_dup_steps = (long long)counters[4];
+    st.beam_ties = (long long)counters[6];
     if (counters[5]) { ctx->detail = "heap replay: producer/consumer hand-shake timed out"; return FV_ERR_DEVICE; }
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
@@ -490,6 +491,25 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     for (int j = 0; j < T; ++j) neg |= path_out[j] < 0;
     if (neg) return beam ? FV_WARN_BEAM_MISS : FV_ERR_NO_PRED;
     return FV_OK;
+}
+
+// A decode that fails after its first enqueue must not leave kernels running on ctx->stream: the next call
+// may grow (hipFree + hipMalloc) a workspace buffer they still use.  Every entry point funnels its error
+// returns through here: end a capture left open, wait for the stream, drop the captured graphs.
+int drained(fv_ctx *ctx, int rc)
+{
+    if (rc >= 0) return rc;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipGraphExec_t ge : ctx->graphs) (void)hipGraphExecDestroy(ge);
+    ctx->graphs.clear();
+    (void)hipGetLastError();          // the failure is reported through rc / detail, not left sticky
+    return rc;
 }
 
 }  // namespace
@@ -618,6 +638,12 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     bool any_big = false;
     for (int k = 0; k < K; ++k) { if (bad[k]) ok_range = false; if (big[k]) any_big = true; }
     if (!ok_range) { ctx->detail = "model entries must be finite and >= 0"; return FV_ERR_ARG; }
+    // From here on device tables are released and overwritten in place: until every upload has succeeded the
+    // context holds NO model (K = 0 makes every decode return FV_ERR_STATE), so a failure half way (e.g. NOMEM
+    // on a larger second model) can never pair the old sizes with partly new tables.
+    ctx->K = 0; ctx->M = 0; ctx->nrows = 0; ctx->full_ok = false;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->LA64R.release(); ctx->LAQ16R.release();
 
     double dmax = 0.0;
     for (int k = 0; k < K; ++k) dmax = std::max(dmax, dmax_row[k]);
@@ -722,8 +748,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LB64T.p, b64.data(), b64.size() * sizeof(double), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok;
-    ctx->LA64R.release(); ctx->LAQ16R.release();      // rebuilt from the new table on the next beam decode
+    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok;     // LA64R / LAQ16R: rebuilt on the next beam decode
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = ms_since(t0);
@@ -749,7 +774,20 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
     }
 }
 
+namespace {
+int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, int *path_out, float *score_out);
+int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode, int *path_out, float *score_out);
+int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *path_out, float *score_out);
+}  // namespace
+
 extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, int *path_out, float *score_out)
+{
+    if (!ctx) return FV_ERR_ARG;
+    return drained(ctx, decode_full_impl(ctx, ob, T, n_split, mode, path_out, score_out));
+}
+
+namespace {
+int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, int *path_out, float *score_out)
 {
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
@@ -798,6 +836,7 @@ extern "C" int fv_decode_full(fv_ctx *ctx, const int *ob, int T, int n_split, in
     ctx->stats.alg_bytes = 4 * ctx->stats.cells;
     return finish_decode(ctx, plan, T, path_out, score_out, t0, nprof, false);
 }
+}  // namespace
 
 namespace {
 
@@ -907,7 +946,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
         f.LA64R = ctx->LA64R.p; f.LB32T = ctx->LB32T.p; f.ob = ctx->d_ob.p;
         f.tie_count = ctx->d_tie_count.p; f.tie_list = ctx->d_tie_list.p; f.tie_cap = (unsigned int)ctx->d_tie_list.n;
         f.slot_val = ctx->d_slot_val.p; f.slot_state = ctx->d_slot_state.p; f.bp = ctx->d_bp.p;
-        f.K = K; f.ld = beam_ld(K); f.beam = beam;
+        f.K = K; f.ld = beam_ld(K); f.beam = beam; f.total = ctx->d_counters.p + 6;
         hipLaunchKernelGGL(fvb::tie_fixup, dim3(512), dim3(256), 0, ctx->stream, f);
         FV_HIP(hipGetLastError());
     }
@@ -927,6 +966,13 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
 
 extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode,
                               int *path_out, float *score_out)
+{
+    if (!ctx) return FV_ERR_ARG;
+    return drained(ctx, decode_beam_impl(ctx, ob, T, n_split, beam_width, mode, path_out, score_out));
+}
+
+namespace {
+int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_width, int mode, int *path_out, float *score_out)
 {
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
@@ -1000,6 +1046,7 @@ extern "C" int fv_decode_beam(fv_ctx *ctx, const int *ob, int T, int n_split, in
     ctx->stats.alg_bytes = 4 * ctx->stats.cells;
     return finish_decode(ctx, plan, T, path_out, score_out, t0, 0, true);
 }
+}  // namespace
 
 extern "C" int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_out, float *score_out)
 {
@@ -1020,6 +1067,13 @@ extern "C" int fv_decode_vanilla(fv_ctx *ctx, const int *ob, int T, int *path_ou
 // the segments are independent, so they advance in lock-step and share table sweeps (up to 8 per launch)
 // instead of running last-to-first as the CPU program does.  End state and back-track as in vanilla.
 extern "C" int fv_decode_checkpoint(fv_ctx *ctx, const int *ob, int T, int step, int *path_out, float *score_out)
+{
+    if (!ctx) return FV_ERR_ARG;
+    return drained(ctx, decode_checkpoint_impl(ctx, ob, T, step, path_out, score_out));
+}
+
+namespace {
+int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *path_out, float *score_out)
 {
     if (!ctx || !ob || !path_out || T < 2) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
@@ -1120,6 +1174,7 @@ extern "C" int fv_decode_checkpoint(fv_ctx *ctx, const int *ob, int T, int step,
     ctx->stats.alg_bytes = 4 * ctx->stats.cells;
     return finish_decode(ctx, plan, T, path_out, score_out, t0, 0, false);
 }
+}  // namespace
 
 extern "C" long long fv_checkpoint_memory_bytes(int K, int T, int step)
 {

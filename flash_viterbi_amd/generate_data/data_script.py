@@ -113,6 +113,43 @@ def make_model64(K, n_ob, seed, prob):
     return make_transition(K, seed, prob), make_emission(K, n_ob, seed), np.full(K, 1 / K)
 
 
+def make_model32_fast(K, n_ob, seed, prob, block=256, workers=None):
+    """float32 (A, B, Pi) of the generate_data distributions for sizes where the generator's own RNG call
+    sequence is too slow to replay (K = 65536: one K-element permutation per row, minutes): every
+    entry of A is an edge with probability `prob` (so a row has Binomial(K, prob) out-edges at uniformly
+    random places, data_script.py:13-17), weights U(0.01, 1), rows normalised (:19-32); B U(0.1, 1)
+    row-normalised (:45-47); Pi = 1/K (:94); every value through the '%.16f' text quantisation the loader
+    applies.  Same distributions, NOT the same random stream: the md5s of SURVEY App. C do not apply.
+    Row blocks are independent (one PCG64 stream per block), produced on a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    from flash_viterbi_amd import hostio
+    if workers is None:
+        try:
+            workers = min(16, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            workers = min(16, os.cpu_count() or 1)
+    A = np.empty((K, K), dtype=np.float32)
+
+    def one(r0):
+        n = min(block, K - r0)
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, r0])))
+        w = g.random((n, K), dtype=np.float32)
+        mask = w < np.float32(prob)
+        blk = np.where(mask, g.uniform(0.01, 1.0, (n, K)), 0.0)
+        empty = ~mask.any(axis=1)
+        if empty.any():                                   # a row without edges cannot be normalised
+            blk[empty, g.integers(0, K, int(empty.sum()))] = 1.0
+        blk /= blk.sum(axis=1)[:, None]
+        A[r0:r0 + n] = hostio.quantize_text16(blk)
+
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(one, range(0, K, block)))
+    g = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, K, n_ob])))
+    B = g.uniform(0.1, 1.0, (K, n_ob))
+    B /= B.sum(axis=1)[:, None]
+    return A, hostio.quantize_text16(B), hostio.quantize_text16(np.full(K, 1 / K))
+
+
 def file_stem(kind, K, T, prob):
     return f"{kind}_K{K}_T{T}_prob{prob}"
 

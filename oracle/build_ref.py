@@ -121,7 +121,9 @@ def run(exe, data_dir, timeout=3600):
 # cpu_baseline sample.  Golden-vector binaries are built on demand by
 # tests/golden/make_golden.py.
 DEFAULT_SET = [
-    dict(kind="flash", K=3965, T=64, prob=0.112, N=8),
+    dict(kind="flash", K=3965, T=256, prob=0.112, N=8),    # cfg2, the bench configuration itself (1 warm + 3 timed)
+    dict(kind="flash", K=3965, T=16, prob=0.112, N=1),     # MAX_THREADS=1 sample
+    dict(kind="flash", K=3965, T=64, prob=0.112, N=8),     # bounded sample of cfg3 (same model, T=4096 sequence)
 ]
 
 if __name__ == "__main__":

@@ -39,42 +39,6 @@ def _ties_semi(K, M, seed):
     return A, B, np.full(K, 1.0 / K)
 
 
-def _sparse_fast32(K, M, seed, prob, block=256, workers=None):
-    """float32 (A, B, Pi) of the generate_data distributions for sizes where the generator's own RNG call
-    sequence is too slow to replay in a test (K = 65536: one K-element permutation per row, minutes): every
-    entry of A is an edge with probability `prob` (so a row has Binomial(K, prob) out-edges at uniformly
-    random places, data_script.py:13-17), weights U(0.01, 1), rows normalised (:19-32); B U(0.1, 1)
-    row-normalised (:45-47); Pi = 1/K (:94); every value through the '%.16f' text quantisation the loader
-    applies.  Same distributions, NOT the same random stream: the md5s of SURVEY App. C do not apply.
-    Row blocks are independent (one PCG64 stream per block), produced on a thread pool."""
-    from concurrent.futures import ThreadPoolExecutor
-    if workers is None:
-        try:
-            workers = min(16, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            workers = min(16, os.cpu_count() or 1)
-    A = np.empty((K, K), dtype=np.float32)
-
-    def one(r0):
-        n = min(block, K - r0)
-        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, r0])))
-        w = g.random((n, K), dtype=np.float32)
-        mask = w < np.float32(prob)
-        blk = np.where(mask, g.uniform(0.01, 1.0, (n, K)), 0.0)
-        empty = ~mask.any(axis=1)
-        if empty.any():                                   # a row without edges cannot be normalised
-            blk[empty, g.integers(0, K, int(empty.sum()))] = 1.0
-        blk /= blk.sum(axis=1)[:, None]
-        A[r0:r0 + n] = hostio.quantize_text16(blk)
-
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        list(ex.map(one, range(0, K, block)))
-    g = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, K, M])))
-    B = g.uniform(0.1, 1.0, (K, M))
-    B /= B.sum(axis=1)[:, None]
-    return A, hostio.quantize_text16(B), hostio.quantize_text16(np.full(K, 1 / K))
-
-
 def model64(spec):
     kind = spec["kind"]
     K, M = spec["K"], spec["M"]
@@ -97,7 +61,7 @@ def observations(spec):
 def model32(spec):
     """(A, B, Pi, ob) in the float32 the reference loader reads from the generator's text."""
     if spec["kind"] == "sparse_fast":
-        A, B, Pi = _sparse_fast32(spec["K"], spec["M"], spec["seed"], spec["prob"])
+        A, B, Pi = data_script.make_model32_fast(spec["K"], spec["M"], spec["seed"], spec["prob"])
         return A, B, Pi, observations(spec)
     A, B, Pi = model64(spec)
     return (hostio.quantize_text16(A), hostio.quantize_text16(B), hostio.quantize_text16(Pi),

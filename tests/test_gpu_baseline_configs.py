@@ -14,7 +14,7 @@ then the library's own choice.
 
 cfg3 / cfg4 use the generate_data random stream (seed 12, as bench.py); cfg5 uses modelgen's
 "sparse_fast" builder — the same distributions from a vectorised random stream, because replaying
-generate_data's per-row K-element permutations takes minutes at K = 65536 (modelgen._sparse_fast32).
+generate_data's per-row K-element permutations takes minutes at K = 65536 (data_script.make_model32_fast).
 """
 import time
 

@@ -75,7 +75,10 @@ struct fv_ctx {
     DevBuf<unsigned short> LAQ16R;                   // row-major fixed-point table of beam_step_q16 (same moment; only when every log <= 0)
     DevBuf<unsigned long long> d_qaux;               // [0] lmax bits, [1] dmax bits, then {qscale, window} as floats (q16_params)
     DevBuf<int2> d_tie_list;
-    DevBuf<float> d_cut;         // [T][2] theta and duplicate flag of every step's heap
+    DevBuf<float> d_cut;         // [T][CUT_W] theta, duplicate flag, predicted lower bound of the next cut (topb_select)
+    DevBuf<fvb::HNode> d_cand;   // [T][cand_cap] candidate lists of the selects (beam_step epilogue)
+    DevBuf<int> d_cand_count;    // [T]
+    float opt_sel_margin = 0.5f; // FV_OPT_SEL_MARGIN (in 1/1000): margin of the predicted cut bound in beam spreads
     DevBuf<int> d_dupwin;        // [T]
     DevBuf<unsigned int> d_tie_count;
 
@@ -116,7 +119,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -484,6 +487,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.beam_dup_cols = (long long)counters[3];
     st.beam_dup_steps = (long long)counters[4];
     st.beam_ties = (long long)counters[6];
+    st.beam_cand_selects = (long long)counters[7];
     if (counters[5]) { ctx->detail = "heap replay: producer/consumer hand-shake timed out"; return FV_ERR_DEVICE; }
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
@@ -562,7 +566,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -768,6 +772,9 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
         ctx->opt_max_batch = (int)value; return FV_OK;
     case FV_OPT_PROFILE:
         ctx->opt_profile = value ? 1 : 0; return FV_OK;
+    case FV_OPT_SEL_MARGIN:
+        if (value < 0 || value > 100000) return FV_ERR_ARG;
+        ctx->opt_sel_margin = (float)value * 1e-3f; return FV_OK;
     case FV_OPT_DEBUG:
         ctx->opt_debug = (int)value; return FV_OK;
     default: return FV_ERR_ARG;
@@ -858,13 +865,17 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
     auto setv_at = [&](int j) { return ctx->d_hval.p + (size_t)j * beam; };
     auto sets_at = [&](int j) { return ctx->d_hstate.p + (size_t)j * beam; };
     FV_HIP(hipMemsetAsync(ctx->d_tie_count.p, 0, sizeof(unsigned int), ctx->stream));
+    const int cand_cap = (ctx->opt_debug & 1024) ? 0 : fvb::cand_cap_for(K, beam);     // FV_OPT_DEBUG bit 10: no candidate lists
+    auto cut_at = [&](int j) { return ctx->d_cut.p + (size_t)j * fvb::CUT_W; };
     auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s
         for (int base = 0; base < count; base += fvb::BEAM_CHUNK) {
             fvb::SelArgs a;
             a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.n = std::min(fvb::BEAM_CHUNK, count - base);
+            a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
-                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), ctx->d_cut.p + (size_t)j * 2 };
+                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), cut_at(j), s >= 1 ? cut_at(j - 1) : nullptr,
+                                      (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
             }
             hipLaunchKernelGGL(fvb::sel_kernel_for(K), dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
             FV_HIP(hipGetLastError());
@@ -897,6 +908,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             a.counters = ctx->d_counters.p;
             a.K = K; a.ld = beam_ld(K); a.ldq = beam_ldq(K); a.beam = beam;
             a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->LAQ16R.p ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
+            a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.cand_cap = cand_cap;
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
@@ -906,7 +918,7 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
                 a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
                 a.p[q].j = j;
-                a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * 2;
+                a.p[q].cut = cut_at(j - 1);
                 a.p[q].dupwin = ctx->d_dupwin.p + j;
             }
             // The 16-bit filter kernel moves a quarter of the bytes but has two more dependent phases (window,
@@ -1001,7 +1013,10 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(ctx->d_slot_state.ensure((size_t)T * beam_width));
     FV_HIP(ctx->d_tie_list.ensure((size_t)T * ctx->K));
     FV_HIP(ctx->d_tie_count.ensure(4));
-    FV_HIP(ctx->d_cut.ensure((size_t)T * 2));
+    FV_HIP(ctx->d_cut.ensure((size_t)T * fvb::CUT_W));
+    FV_HIP(ctx->d_cand_count.ensure(T));
+    FV_HIP(hipMemsetAsync(ctx->d_cand_count.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    if (const int cap = fvb::cand_cap_for(ctx->K, beam_width)) FV_HIP(ctx->d_cand.ensure((size_t)T * cap));
     FV_HIP(ctx->d_dupwin.ensure(T));
     FV_HIP(hipMemsetAsync(ctx->d_dupwin.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (!ctx->LA64R.p) {

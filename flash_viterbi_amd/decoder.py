@@ -14,7 +14,7 @@ from . import build as _build
 MODE_REFERENCE = 0
 MODE_SINGLE_PASS = 1
 KERNEL_AUTO, KERNEL_F64_STREAM, KERNEL_F32_REFINE, KERNEL_F16_REFINE, KERNEL_Q16_REFINE, KERNEL_SPARSE_Q16 = 0, 1, 2, 3, 4, 5
-OPT_KERNEL, OPT_MAX_BATCH, OPT_PROFILE, OPT_DEBUG = 1, 2, 3, 100
+OPT_KERNEL, OPT_MAX_BATCH, OPT_PROFILE, OPT_SEL_MARGIN, OPT_DEBUG = 1, 2, 3, 4, 100
 WARN_BEAM_MISS = 1
 UNIQUE_ID_BYTES = 128
 
@@ -29,7 +29,8 @@ class Stats(ctypes.Structure):
                 ("table_bytes_per_step", ctypes.c_longlong), ("device_bytes", ctypes.c_longlong),
                 ("refine_near", ctypes.c_longlong), ("refine_rescan", ctypes.c_longlong),
                 ("beam_exact_sets", ctypes.c_longlong), ("beam_ties", ctypes.c_longlong),
-                ("beam_dup_cols", ctypes.c_longlong), ("beam_dup_steps", ctypes.c_longlong), ("density", ctypes.c_double),
+                ("beam_dup_cols", ctypes.c_longlong), ("beam_dup_steps", ctypes.c_longlong),
+                ("beam_cand_selects", ctypes.c_longlong), ("density", ctypes.c_double),
                 ("passes", ctypes.c_int), ("generations", ctypes.c_int), ("kernel", ctypes.c_int),
                 ("ranks", ctypes.c_int)]
 

@@ -55,6 +55,8 @@ enum {
     FV_OPT_KERNEL = 1,      /* FV_KERNEL_* : which trellis-step kernel streams the transition table */
     FV_OPT_MAX_BATCH = 2,   /* 1..8: most independent tasks advanced by one step launch */
     FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
+    FV_OPT_SEL_MARGIN = 4,  /* FLASH-BS: margin, in 1/1000 of the beam spread (max - cut value), below the extrapolated cut value
+                               from which the step kernels collect the next select's candidates (default 500); speed only */
     FV_OPT_DEBUG = 100,     /* kernel-tuning switches for timing experiments only (bit0 voids results) */
 };
 enum {
@@ -93,6 +95,7 @@ typedef struct {
     long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order */
     long long beam_dup_cols;  /* FLASH-BS statistics: columns won by an entry whose value equals a duplicated cut value */
     long long beam_dup_steps; /* ... and the number of steps in which that happened at least once */
+    long long beam_cand_selects; /* FLASH-BS: top-B selections that ran on a step's candidate list instead of all K scores */
     double density;           /* non-zero fraction of the transition matrix */
     int passes;               /* forward passes run (reference mode: one per right-hand task) */
     int generations;          /* dependent batches of passes */

@@ -14,6 +14,7 @@ from . import build as _build
 MODE_REFERENCE = 0
 MODE_SINGLE_PASS = 1
 KERNEL_AUTO, KERNEL_F64_STREAM, KERNEL_F32_REFINE, KERNEL_F16_REFINE, KERNEL_Q16_REFINE, KERNEL_SPARSE_Q16 = 0, 1, 2, 3, 4, 5
+KERNEL_U16_REFINE = 6
 OPT_KERNEL, OPT_MAX_BATCH, OPT_PROFILE, OPT_SEL_MARGIN, OPT_DEBUG = 1, 2, 3, 4, 100
 WARN_BEAM_MISS = 1
 UNIQUE_ID_BYTES = 128

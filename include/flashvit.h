@@ -70,6 +70,10 @@ enum {
                                   window costs more refines than the bytes save at K=3965 */
     FV_KERNEL_Q16_REFINE = 4,  /* same scheme with 16-bit fixed point (step = max|log A|/65534): 2 B/cell and
                                   a window ~ step: same bits out */
+    FV_KERNEL_U16_REFINE = 6,  /* the Q16 table again, but the filter itself runs in 16-bit fixed point, two cells per packed
+                                  instruction (the score row is quantised with the table's step while it is staged into LDS);
+                                  candidates inside the window are re-evaluated in float64 as above: same bits out.  The
+                                  f32 filters are VALU-issue-bound; this one needs ~half their instructions per cell */
     FV_KERNEL_SPARSE_Q16 = 5,  /* the Q16 codes of the NON-ZERO transitions only (per destination column, ascending
                                   source state): log 0 = -inf can never win (FLASH:171), so skipping those cells
                                   changes no bit; 7.6 MB instead of 31.5 MB at K=3965, p=0.112 */

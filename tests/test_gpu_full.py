@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 PAIRS, IDS = golden_runs(include_big=True, algo="flash")
 KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE, decoder.KERNEL_Q16_REFINE,
-           decoder.KERNEL_SPARSE_Q16]
-KIDS = ["f64stream", "f32refine", "f16refine", "q16refine", "sparseq16"]
+           decoder.KERNEL_SPARSE_Q16, decoder.KERNEL_U16_REFINE]
+KIDS = ["f64stream", "f32refine", "f16refine", "q16refine", "sparseq16", "u16refine"]
 
 
 @pytest.fixture(scope="module")

@@ -68,7 +68,6 @@ struct fv_ctx {
     DevBuf<int> d_ob, d_ans, d_bp, d_gather;
     DevBuf<float> d_rows, d_score, d_ckpt;            // d_ckpt: kept score rows of fv_decode_checkpoint
     DevBuf<unsigned long long> d_counters;
-    DevBuf<int> d_rowmax;                             // packed 16-bit kernel: 3 rotating row-maximum words per pass
     // beam workspace
     DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
     DevBuf<int> d_hstate, d_slot_state, d_flags;
@@ -118,7 +117,7 @@ size_t device_bytes(const fv_ctx *c)
 {
     return c->LA32.bytes() + c->LA16.bytes() + c->LAQ16.bytes() + c->SPdata.bytes() + c->SPoff.bytes() + c->SPnwb.bytes() + c->LB32T.bytes() + c->LA64.bytes() + c->LB64T.bytes() + c->LPi64.bytes() +
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
-           c->d_score.bytes() + c->d_counters.bytes() + c->d_rowmax.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
+           c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
            c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes();
 }
@@ -250,10 +249,11 @@ int launch_sparse(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb)
     return launch_sparse_nb<8>(ctx, slots, nb);
 }
 
-template <int NB, int U, bool DB>
-int launch_u16_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
+template <int NB, int U, bool DB, int NWV>
+int launch_u16_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a)
 {
-    hipLaunchKernelGGL((fvk::trellis_step_u16<NB, U, DB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    const size_t lds = fvk::u16_lds_bytes<NB, NWV>(ctx->nrows);
+    hipLaunchKernelGGL((fvk::trellis_step_u16<NB, U, DB, NWV>), dim3(a.tiles_per_xcd * 8), dim3(NWV * 64), lds, ctx->stream, a);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -270,12 +270,15 @@ int launch_u16_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     a.nb = nb;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
-    const size_t lds = fvk::u16_lds_bytes<NB>(ctx->nrows);
-    const int nj_max = (ctx->nrows / 32 + fvk::NWAVES - 1) / fvk::NWAVES;
-    // whole tile share requested up front (one workgroup per CU) while the grid fits the chip in one round,
-    // else the double-buffered variant (fewer registers, two workgroups per CU) — as for the f32 filter on this table
-    if (nj_max <= U_UP && a.ntiles <= ctx->num_cus && !(ctx->opt_debug & 4)) return launch_u16_variant<NB, U_UP, false>(ctx, a, lds);
-    return launch_u16_variant<NB, U_DB16, true>(ctx, a, lds);
+    const int nq = ctx->nrows / 32;
+    // 8 waves per workgroup (FV_OPT_DEBUG bit 13: 16): everything outside the sweep — quantisation, reductions, refine —
+    // is executed by every wave, so fewer, longer waves spend fewer issue slots on it
+    if (ctx->opt_debug & 8192) {
+        if (a.ntiles <= ctx->num_cus && (nq + 15) / 16 <= 8 && !(ctx->opt_debug & 4)) return launch_u16_variant<NB, 8, false, 16>(ctx, a);
+        return launch_u16_variant<NB, U_DB16, true, 16>(ctx, a);
+    }
+    if (a.ntiles <= ctx->num_cus && (nq + 7) / 8 <= 16 && !(ctx->opt_debug & 4)) return launch_u16_variant<NB, 16, false, 8>(ctx, a);
+    return launch_u16_variant<NB, U_DB16, true, 8>(ctx, a);
 }
 
 int launch_u16(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
@@ -346,7 +349,6 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
     }
     FV_HIP(ctx->d_score.ensure(4));
     FV_HIP(ctx->d_counters.ensure(8));
-    FV_HIP(ctx->d_rowmax.ensure(rows_needed * 3));
     if (ctx->comm) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
     return 0;
 }
@@ -373,21 +375,17 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     if (np == 0) return 0;
     std::stable_sort(passes.begin(), passes.end(),
                      [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
-    // packed 16-bit kernel: three rotating row-maximum words per pass, all -inf before the init rows accumulate into word 0
-    const bool u16 = kernel == FV_KERNEL_U16_REFINE;
-    if (u16) FV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_rowmax.p), fvk::ORD_NEG_INF, (size_t)np * 3, ctx->stream));
-    auto rmax = [&](int q, int s) { return ctx->d_rowmax.p + (size_t)q * 3 + (s % 3); };
     // init rows
     for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
         fvk::PassChunk ch;
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
         for (int q = 0; q < ch.n; ++q) {
             const fv::Pass &p = passes[base + q];
-            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * ctx->nrows, (base + q) * 3 };
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)(base + q) * 2 * ctx->nrows };
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
                            ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
-                           ctx->d_rows.p, K, u16 ? ctx->d_rowmax.p : nullptr);
+                           ctx->d_rows.p, K);
         FV_HIP(hipGetLastError());
     }
     const int maxlen = passes[0].R - passes[0].L;
@@ -416,9 +414,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                 slots[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].tmp64_row = ctx->LB64T.p + (size_t)ctx->h_ob[p.L + s] * K;
                 slots[q].bp_out = ctx->d_bp.p + (size_t)(p.L + s) * K;
-                slots[q].rmax_in = u16 ? rmax(base + q, s - 1) : nullptr;
-                slots[q].rmax_out = u16 ? rmax(base + q, s) : nullptr;
-                slots[q].rmax_reset = u16 ? rmax(base + q, s + 1) : nullptr;
             }
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (ctx->opt_profile) {
@@ -472,7 +467,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
         for (int q = 0; q < ch.n; ++q) {
             const fv::Pass &p = passes[base + q];
-            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, 0, -1 };
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, 0 };
         }
         hipLaunchKernelGGL(fvk::backtrack, dim3(ch.n), dim3(64), 0, ctx->stream, ch, ctx->d_bp.p, K, ctx->d_ans.p);
         FV_HIP(hipGetLastError());
@@ -597,10 +592,14 @@ extern "C" int fv_create(fv_ctx **out, int device)
         (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<1>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<2>)) ||
         (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<4>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_sparse<8>)))
         return fail(rc);
-    if ((rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, U_UP, false>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, U_DB16, true>)) ||
-        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, U_UP, false>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, U_DB16, true>)) ||
-        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, U_UP, false>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, U_DB16, true>)) ||
-        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, U_UP, false>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, U_DB16, true>)))
+    if ((rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, 8, false, 16>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, U_DB16, true, 16>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, 8, false, 16>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, U_DB16, true, 16>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, 8, false, 16>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, U_DB16, true, 16>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, 8, false, 16>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, U_DB16, true, 16>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<1, U_DB16, true, 8>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<2, U_DB16, true, 8>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, U_DB16, true, 8>)) ||
+        (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, U_DB16, true, 8>)))
         return fail(rc);
     if ((rc = fvb::allow_big_lds(ctx->detail))) return fail(rc);
     *out = ctx;
@@ -615,7 +614,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     if (ctx->comm) ncclCommDestroy(ctx->comm);
     ctx->LA32.release(); ctx->LA16.release(); ctx->LAQ16.release(); ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release(); ctx->LB32T.release(); ctx->LA64.release(); ctx->LB64T.release(); ctx->LPi64.release();
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
-    ctx->d_score.release(); ctx->d_counters.release(); ctx->d_rowmax.release(); ctx->d_hval.release(); ctx->d_scores.release();
+    ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
     ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -939,11 +938,11 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
         for (int q = 0; q < ch.n; ++q) {
             const fv::Pass &p = passes[base + q];
-            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)p.L * K, -1 };
+            ch.p[q] = fvk::PassDesc{ p.L, p.R, p.from_pi ? 1 : 0, p.whole ? 1 : 0, (long long)p.L * K };
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
                            ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
-                           ctx->d_scores.p, K, (int *)nullptr);
+                           ctx->d_scores.p, K);
         FV_HIP(hipGetLastError());
     }
     int rc = select(np, 0);
@@ -1182,15 +1181,14 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
         sl.tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
         sl.tmp64_row = ctx->LB64T.p + (size_t)ctx->h_ob[j] * K;
         sl.bp_out = ctx->d_bp.p + (size_t)j * K;
-        sl.rmax_in = nullptr; sl.rmax_out = nullptr; sl.rmax_reset = nullptr;
         return sl;
     };
     {   // initT1 (:119) into checkpoint 0
         fvk::PassChunk ch;
         ch.n = 1;
-        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0, -1 };
+        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0 };
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, 1), dim3(256), 0, ctx->stream, ch, ctx->LA64.p, nrows,
-                           ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p, ctx->d_ckpt.p, K, (int *)nullptr);
+                           ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p, ctx->d_ckpt.p, K);
         FV_HIP(hipGetLastError());
     }
     // first pass (:213-232)
@@ -1233,7 +1231,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
     {
         fvk::PassChunk ch;
         ch.n = 1;
-        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0, -1 };
+        ch.p[0] = fvk::PassDesc{ 0, T - 1, 1, 1, 0 };
         hipLaunchKernelGGL(fvk::backtrack, dim3(1), dim3(64), 0, ctx->stream, ch, ctx->d_bp.p, K, ctx->d_ans.p);
         FV_HIP(hipGetLastError());
     }

@@ -927,7 +927,9 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
                 a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), cut_at(j), s >= 1 ? cut_at(j - 1) : nullptr,
                                       (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
             }
-            hipLaunchKernelGGL(fvb::sel_kernel_for(K), dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
+            // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
+            fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap) : nullptr;
+            hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K), dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
             FV_HIP(hipGetLastError());
         }
         return 0;

@@ -60,7 +60,8 @@ WORKLOADS = {
 }
 KERNEL_NAMES = {1: "fvk::trellis_step<double,1,2,true>", 2: "fvk::trellis_step<float,1,4,true>",
                 3: "fvk::trellis_step<fvk::half_t,1,16,false>", 4: "fvk::trellis_step<fvk::q16_t,1,16,false>",
-                5: "fvk::trellis_step_sparse<1>"}
+                5: "fvk::trellis_step_sparse<1>", 6: "fvk::trellis_step_u16<1,16,false,8>"}
+DENSE_KERNEL = decoder.KERNEL_U16_REFINE      # the library's AUTO choice for a dense model: 16-bit table, every K*K cell swept
 
 
 def build_workload(w):
@@ -231,7 +232,7 @@ def main():
         # this model is the sparse walk (non-zero transitions only, same bits out); it is measured afterwards
         # and reported as `sparse_walk`, never as `value`.
         if not is_beam:
-            d.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+            d.set_option(decoder.OPT_KERNEL, DENSE_KERNEL)
         return d
 
     fv = new_decoder()
@@ -337,7 +338,7 @@ def main():
                 "note": "only the non-zero transitions are stored and visited (log 0 = -inf can never win, "
                         "reference FLASH_Viterbi_multithread.c:171): bit-identical output, fewer cells evaluated; "
                         "not comparable with the HBM roofline of the K*K sweep"}
-        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+        fv.set_option(decoder.OPT_KERNEL, DENSE_KERNEL)
 
     if rank == 0:
         cells = K * K * T
@@ -356,7 +357,8 @@ def main():
                        "model_generator": "generate_data random stream (data_script.py -s 12)" if w["gen"] == "data_script"
                                           else "data_script.make_model32_fast (same distributions, vectorised random stream)",
                        "kernel": ("beam_step / beam_step_q16 by launch size" if is_beam else
-                                  {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16"}[st["kernel"]]),
+                                  {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16",
+                                   6: "u16_refine (packed 16-bit filter on single-task launches, f32 filter on batched ones; same 16-bit table)"}[st["kernel"]]),
                        "kernel_note": (None if is_beam else "dense K*K sweep forced for value/roofline; the library's AUTO choice for this "
                                        "model is the sparse walk, reported separately as sparse_walk"),
                        "transition_density": st["density"] if not is_beam else None,

@@ -53,7 +53,8 @@ struct fv_ctx {
 
     // model
     int K = 0, M = 0, nrows = 0;
-    bool full_ok = false;    // the full-state kernels can take this K (one score row fits LDS)
+    bool full_ok = false;    // every full-state kernel can take this K (one float32 score row fits LDS: K <= ~38000)
+    bool u16_ok = false;     // the packed 16-bit kernel can (one row of 16-bit score codes fits LDS: K <= 65536)
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
     DevBuf<unsigned short> LA16, LAQ16;
@@ -151,9 +152,9 @@ int pick_kernel(const fv_ctx *ctx)
     if (ctx->opt_kernel == FV_KERNEL_F16_REFINE || ctx->opt_kernel == FV_KERNEL_F32_REFINE ||
         ctx->opt_kernel == FV_KERNEL_Q16_REFINE || ctx->opt_kernel == FV_KERNEL_U16_REFINE)
         return ctx->opt_kernel;
-    if (ctx->opt_kernel == FV_KERNEL_SPARSE_Q16) return ctx->SPdata.p ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_Q16_REFINE;
+    if (ctx->opt_kernel == FV_KERNEL_SPARSE_Q16) return ctx->SPdata.p ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_U16_REFINE;
     // AUTO: the sparse walk visits only finite entries; it wins clearly below ~1/3 density
-    return (ctx->SPdata.p && ctx->density <= 0.35) ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_Q16_REFINE;
+    return (ctx->SPdata.p && ctx->density <= 0.35) ? FV_KERNEL_SPARSE_Q16 : FV_KERNEL_U16_REFINE;
 }
 
 // Kernel variants: chunks of U 16-byte loads per lane, double-buffered in registers.
@@ -292,7 +293,14 @@ int launch_u16(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
 int launch_step_kernel(fv_ctx *ctx, int kernel, const fvk::TaskSlot *slots, int nb, int reverse)
 {
     switch (kernel) {
-    case FV_KERNEL_U16_REFINE: return launch_u16(ctx, slots, nb, reverse);
+    case FV_KERNEL_U16_REFINE:
+        // Both filters read the same 16-bit table and give the same bits, so the choice is per launch: the packed
+        // 16-bit filter for single-task launches (the whole-sequence pass: 9.1 vs 9.3 us per step at K=3965/T=256,
+        // 10.4 vs 14.2 at T=4096 where its window is the narrower one) and for models whose float32 rows do not fit
+        // LDS; the f32 filter for batched launches, where the 16-bit kernel's per-task prologue (row maximum,
+        // quantisation) costs what its cheaper sweep saves.  FV_OPT_DEBUG bit 14: packed 16-bit for every launch.
+        if (nb <= 1 || !ctx->full_ok || (ctx->opt_debug & 16384)) return launch_u16(ctx, slots, nb, reverse);
+        return launch_step<fvk::q16_t>(ctx, slots, nb, reverse);
     case FV_KERNEL_SPARSE_Q16: return launch_sparse(ctx, slots, nb);
     case FV_KERNEL_F64_STREAM: return launch_step<double>(ctx, slots, nb, reverse);
     case FV_KERNEL_F32_REFINE: return launch_step<float>(ctx, slots, nb, reverse);
@@ -323,8 +331,14 @@ int allow_big_lds(fv_ctx *ctx)
 }
 
 // largest batch whose score rows fit LDS next to the reduction scratch
-int max_batch_for(int nrows)
+int max_batch_for(int nrows, bool u16_only)
 {
+    if (u16_only) {             // models beyond the float32 kernels' limit: rows of 16-bit codes
+        if (fvk::u16_lds_bytes<8, 8>(nrows) <= 160 * 1024) return 8;
+        if (fvk::u16_lds_bytes<4, 8>(nrows) <= 160 * 1024) return 4;
+        if (fvk::u16_lds_bytes<2, 8>(nrows) <= 160 * 1024) return 2;
+        return 1;
+    }
     int nb = fvk::MAX_BATCH;
     while (nb > 1) {
         size_t need = nb == 8 ? fvk::step_lds_bytes<8>(nrows) : nb == 4 ? fvk::step_lds_bytes<4>(nrows)
@@ -389,7 +403,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         FV_HIP(hipGetLastError());
     }
     const int maxlen = passes[0].R - passes[0].L;
-    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows)));
+    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows, !ctx->full_ok)));
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
     const bool col_last = !(ctx->opt_debug & 8);  // FV_OPT_DEBUG bit 3: run every last step as a full step
     // FV_OPT_DEBUG bit 6 (experiment): capture this generation's step launches into a hipGraph and replay it
@@ -637,6 +651,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     // the full-state step kernels keep one score row in LDS: beyond that K only the beam path is available
     // (it needs the float64 table alone, which also keeps the host footprint at 8 B per entry)
     const bool full_ok = fvk::step_lds_bytes<1>(nrows) <= 160 * 1024;
+    const bool u16_ok = fvk::u16_lds_bytes<1, 8>(nrows) <= 160 * 1024 && K <= 65536;
 
     const size_t tab = (size_t)ntiles * nrows * fvk::TILE_W;
     std::vector<double> h64;
@@ -695,7 +710,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     // From here on device tables are released and overwritten in place: until every upload has succeeded the
     // context holds NO model (K = 0 makes every decode return FV_ERR_STATE), so a failure half way (e.g. NOMEM
     // on a larger second model) can never pair the old sizes with partly new tables.
-    ctx->K = 0; ctx->M = 0; ctx->nrows = 0; ctx->full_ok = false;
+    ctx->K = 0; ctx->M = 0; ctx->nrows = 0; ctx->full_ok = false; ctx->u16_ok = false;
     (void)hipStreamSynchronize(ctx->stream);
     ctx->LA64R.release(); ctx->LAQ16R.release();
 
@@ -802,7 +817,7 @@ extern "C" int fv_set_model(fv_ctx *ctx, const float *A, const float *B, const f
     FV_HIP(hipMemcpy(ctx->LB64T.p, b64.data(), b64.size() * sizeof(double), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LB32T.p, b32.data(), b32.size() * sizeof(float), hipMemcpyHostToDevice));
     FV_HIP(hipMemcpy(ctx->LPi64.p, pi64.data(), pi64.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok;     // LA64R / LAQ16R: rebuilt on the next beam decode
+    ctx->K = K; ctx->M = M; ctx->nrows = nrows; ctx->full_ok = full_ok; ctx->u16_ok = u16_ok;     // LA64R / LAQ16R: rebuilt on the next beam decode
     ctx->logs_nonpositive = !any_big;
     ctx->stats = fv_stats{};
     ctx->stats.set_model_ms = ms_since(t0);
@@ -848,7 +863,13 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
 {
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
-    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~38000)"; return FV_ERR_UNSUPPORTED; }
+    // Beyond the float32 kernels' LDS limit only the packed 16-bit kernel fits (a row of 16-bit score codes is half
+    // the bytes): it needs every model entry in [0,1] and its table is built on the device on first use.
+    const bool big = !ctx->full_ok;
+    if (big && !(ctx->u16_ok && ctx->logs_nonpositive && (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_U16_REFINE))) {
+        ctx->detail = "full-state decode of K > ~38000 needs the packed 16-bit kernel (FV_KERNEL_AUTO / FV_KERNEL_U16_REFINE, K <= 65536, model entries in [0,1])";
+        return FV_ERR_UNSUPPORTED;
+    }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     if (ctx->opt_kernel >= FV_KERNEL_F32_REFINE && !ctx->logs_nonpositive) {
         ctx->detail = "the filter+refine kernels need every model entry in [0,1]";
@@ -859,7 +880,26 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     fv::Plan plan;
     int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
     if (rc) return rc;
-    const int kernel = pick_kernel(ctx);
+    const int kernel = big ? FV_KERNEL_U16_REFINE : pick_kernel(ctx);
+    if (big && !ctx->LAQ16.p) {
+        const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
+        const size_t tab = (size_t)ntiles * ctx->nrows * fvk::TILE_W;
+        FV_HIP(ctx->LAQ16.ensure(tab));
+        FV_HIP(ctx->d_qaux.ensure(3));
+        FV_HIP(hipMemsetAsync(ctx->d_qaux.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(fvk::q16_tile_range, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, tab, ctx->d_qaux.p);
+        hipLaunchKernelGGL(fvk::q16_tile_codes, dim3(4096), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LAQ16.p, ctx->K, ctx->nrows,
+                           ntiles, ctx->d_qaux.p, ctx->d_qaux.p + 1);
+        FV_HIP(hipGetLastError());
+        unsigned long long bits[2] = { 0, 0 };
+        FV_HIP(hipMemcpyAsync(bits, ctx->d_qaux.p, sizeof bits, hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(hipStreamSynchronize(ctx->stream));
+        double lmax, dqmax;
+        std::memcpy(&lmax, &bits[0], 8); std::memcpy(&dqmax, &bits[1], 8);
+        const float stepf = lmax > 0.0 ? (float)(lmax / 65534.0) : 1.0f;
+        ctx->windowq = std::nextafter((float)(2.0 * dqmax), HUGE_VALF);
+        ctx->qscale = -stepf;
+    }
 
     // generations of passes this rank runs
     std::vector<std::vector<fv::Pass>> gens(plan.generations());
@@ -1209,7 +1249,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
     for (int c = 0; c < nck; ++c) order[c] = c;
     auto seg_len = [&](int c) { return std::min((c + 1) * step, T - 1) - c * step; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return seg_len(a) > seg_len(b); });
-    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(nrows)));
+    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(nrows, false)));
     const int maxlen = seg_len(order[0]);
     int active = nck;
     for (int s = 1; s <= maxlen; ++s) {

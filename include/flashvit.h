@@ -60,7 +60,7 @@ enum {
     FV_OPT_DEBUG = 100,     /* kernel-tuning switches for timing experiments only (bit0 voids results) */
 };
 enum {
-    FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else Q16_REFINE;
+    FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else U16_REFINE;
                                   otherwise F64_STREAM */
     FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim */
     FV_KERNEL_F32_REFINE = 2,  /* streams (float)log A (4 B/cell), brackets the winner within 2 ulp,
@@ -72,8 +72,9 @@ enum {
                                   a window ~ step: same bits out */
     FV_KERNEL_U16_REFINE = 6,  /* the Q16 table again, but the filter itself runs in 16-bit fixed point, two cells per packed
                                   instruction (the score row is quantised with the table's step while it is staged into LDS);
-                                  candidates inside the window are re-evaluated in float64 as above: same bits out.  The
-                                  f32 filters are VALU-issue-bound; this one needs ~half their instructions per cell */
+                                  candidates inside the window are re-evaluated in float64 as above: same bits out.  Used
+                                  for single-task launches (the whole-sequence pass) and for models whose float32 rows do not
+                                  fit LDS (K up to 65536); batched launches take the Q16_REFINE filter (same table, same bits) */
     FV_KERNEL_SPARSE_Q16 = 5,  /* the Q16 codes of the NON-ZERO transitions only (per destination column, ascending
                                   source state): log 0 = -inf can never win (FLASH:171), so skipping those cells
                                   changes no bit; 7.6 MB instead of 31.5 MB at K=3965, p=0.112 */

@@ -95,6 +95,34 @@ def test_cfg3_full_decode_equals_oracle():
         assert rc == 0 and path.tolist() == opath.tolist() and score == oscore, kernel
 
 
+def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
+    """one float32 score row of K = 40000 states no longer fits LDS (the f32 kernels stop at
+    K ~ 38000); a row of 16-bit score codes does, so the packed 16-bit kernel takes over (its table is built on the
+    device on first use).  The reference sizes everything from K_STATE and has no such ceiling
+    (src/FLASH_Viterbi_multithread.c:25-34)."""
+    spec = dict(kind="sparse_fast", K=40000, M=20, T=8, prob=0.02, seed=31)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    fv = decoder.FlashViterbi(0)
+    try:
+        fv.set_model(A, Bm, Pi)
+        path, score, rc = fv.decode_full(ob, 1, decoder.MODE_REFERENCE)
+        st = fv.stats()
+        assert st["kernel"] == decoder.KERNEL_U16_REFINE
+        _log(f"K=40000 full decode gpu_ms {st['gpu_ms']:.1f} passes {st['passes']}")
+        path3, score3, rc3 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
+        with pytest.raises(decoder.FlashVitError):
+            fv.decode_full(ob, 1)                          # the other kernels still say UNSUPPORTED
+    finally:
+        fv.close()
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.full_decode(ob, 1)
+    opath3, oscore3, _, _ = om.full_decode(ob, 3)
+    om.close()
+    assert rc == 0 and orc == 0 and path.tolist() == opath.tolist() and score == oscore
+    assert rc3 == 0 and path3.tolist() == opath3.tolist() and score3 == oscore3
+
+
 def test_cfg4_beam_decode_equals_oracle():
     """BASELINE configs[3]: K=16384, T=256, B=256, n_split=8 (127 passes, batched launches, in-kernel replays)."""
     _beam_case(dict(kind="data_script", K=16384, M=50, T=256, prob=0.112, seed=12), 8, 256, partition_check=True)

@@ -48,6 +48,21 @@ def test_reference_mode_matches_golden(ctxs, g, r, kernel):
 
 
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_packed_u16_filter_for_batched_launches_matches_golden(ctxs, g, r):
+    """FV_KERNEL_U16_REFINE uses the packed 16-bit filter for single-task launches only; FV_OPT_DEBUG bit 14 forces
+    it for the batched (right-hand) launches too, bit 13 selects its 16-wave workgroup form."""
+    fv, ob = ctxs(g)
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_U16_REFINE)
+    for dbg in (16384, 16384 | 8192, 16384 | 4):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+
+
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_single_pass_mode_matches_golden_empirically(ctxs, g, r):
     """Not guaranteed by construction (different rounding history for right-hand tasks) but it
     holds on every fixture; a failure here is information, not necessarily a bug."""

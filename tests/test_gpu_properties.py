@@ -47,10 +47,15 @@ def test_cfg3_all_kernels_and_schedules_agree(cfg3):
     A, B, Pi, ob, fv = cfg3
     fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
     ref_path, ref_score, _ = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
-    for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F64_STREAM):
+    for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_U16_REFINE, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F64_STREAM):
         fv.set_option(decoder.OPT_KERNEL, kernel)
         path, score, rc = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
         assert rc == 0 and (path == ref_path).all() and score == ref_score, kernel
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_U16_REFINE)
+    fv.set_option(decoder.OPT_DEBUG, 16384)          # packed 16-bit filter for the batched launches too
+    path, score, rc = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
+    fv.set_option(decoder.OPT_DEBUG, 0)
+    assert rc == 0 and (path == ref_path).all() and score == ref_score
     fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
     # other segmentations replay different passes but must land on the same optimum here
     for n in (1, 16):
@@ -78,7 +83,7 @@ def test_cfg3_beam_path_valid_and_not_better_than_full(cfg3):
             assert s64 <= float(full_score) + 1e-5 * abs(float(full_score))   # a pruned search cannot beat the optimum
 
 
-@pytest.mark.parametrize("prob,expect", [(0.9, decoder.KERNEL_Q16_REFINE), (0.5, decoder.KERNEL_Q16_REFINE),
+@pytest.mark.parametrize("prob,expect", [(0.9, decoder.KERNEL_U16_REFINE), (0.5, decoder.KERNEL_U16_REFINE),
                                          (0.3, decoder.KERNEL_SPARSE_Q16)])
 def test_auto_kernel_choice_by_density_and_parity(prob, expect):
     """Dense models take the dense 16-bit table, sparse ones the walk; both equal the oracle."""
@@ -93,10 +98,14 @@ def test_auto_kernel_choice_by_density_and_parity(prob, expect):
     st = fv.stats()
     assert st["kernel"] == expect and abs(st["density"] - prob) < 0.03
     assert rc == 0 and path.tolist() == opath.tolist() and score == oscore
-    for kernel in (decoder.KERNEL_SPARSE_Q16, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F16_REFINE):
+    for kernel in (decoder.KERNEL_SPARSE_Q16, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F16_REFINE, decoder.KERNEL_U16_REFINE):
         fv.set_option(decoder.OPT_KERNEL, kernel)
         path, score, rc = fv.decode_full(ob, 4)
         assert path.tolist() == opath.tolist() and score == oscore
+    fv.set_option(decoder.OPT_DEBUG, 16384)          # packed 16-bit filter for the batched launches too
+    path, score, rc = fv.decode_full(ob, 4)
+    fv.set_option(decoder.OPT_DEBUG, 0)
+    assert path.tolist() == opath.tolist() and score == oscore
     bo, bs, _, brc = om.beam_decode(ob, 4, 40)
     bp, bsc, rc = fv.decode_beam(ob, 4, 40)
     assert bp.tolist() == bo.tolist() and bsc == bs and rc == brc

@@ -53,7 +53,7 @@ struct fv_ctx {
 
     // model
     int K = 0, M = 0, nrows = 0;
-    bool full_ok = false;    // every full-state kernel can take this K (one float32 score row fits LDS: K <= ~38000)
+    bool full_ok = false;    // every full-state kernel can take this K (one float32 score row fits LDS: K <= ~40100)
     bool u16_ok = false;     // the packed 16-bit kernel can (one row of 16-bit score codes fits LDS: K <= 65536)
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
@@ -867,7 +867,7 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     // the bytes): it needs every model entry in [0,1] and its table is built on the device on first use.
     const bool big = !ctx->full_ok;
     if (big && !(ctx->u16_ok && ctx->logs_nonpositive && (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_U16_REFINE))) {
-        ctx->detail = "full-state decode of K > ~38000 needs the packed 16-bit kernel (FV_KERNEL_AUTO / FV_KERNEL_U16_REFINE, K <= 65536, model entries in [0,1])";
+        ctx->detail = "full-state decode of K > ~40100 needs the packed 16-bit kernel (FV_KERNEL_AUTO / FV_KERNEL_U16_REFINE, K <= 65536, model entries in [0,1])";
         return FV_ERR_UNSUPPORTED;
     }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
@@ -1184,7 +1184,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
 {
     if (!ctx || !ob || !path_out || T < 2) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
-    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~38000)"; return FV_ERR_UNSUPPORTED; }
+    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~40100)"; return FV_ERR_UNSUPPORTED; }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     if (step <= 0) step = (int)std::floor(std::sqrt(1.0 * T));        // checkpoint Viterbi.c:179-180
     auto t0 = clk::now();

@@ -96,11 +96,11 @@ def test_cfg3_full_decode_equals_oracle():
 
 
 def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
-    """one float32 score row of K = 40000 states no longer fits LDS (the f32 kernels stop at
-    K ~ 38000); a row of 16-bit score codes does, so the packed 16-bit kernel takes over (its table is built on the
+    """one float32 score row of K = 44000 states no longer fits LDS (the f32 kernels stop at
+    K ~ 40100); a row of 16-bit score codes does, so the packed 16-bit kernel takes over (its table is built on the
     device on first use).  The reference sizes everything from K_STATE and has no such ceiling
     (src/FLASH_Viterbi_multithread.c:25-34)."""
-    spec = dict(kind="sparse_fast", K=40000, M=20, T=8, prob=0.02, seed=31)
+    spec = dict(kind="sparse_fast", K=44000, M=20, T=8, prob=0.02, seed=31)
     A, Bm, Pi, ob = modelgen.model32(spec)
     fv = decoder.FlashViterbi(0)
     try:
@@ -108,7 +108,7 @@ def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
         path, score, rc = fv.decode_full(ob, 1, decoder.MODE_REFERENCE)
         st = fv.stats()
         assert st["kernel"] == decoder.KERNEL_U16_REFINE
-        _log(f"K=40000 full decode gpu_ms {st['gpu_ms']:.1f} passes {st['passes']}")
+        _log(f"K=44000 full decode gpu_ms {st['gpu_ms']:.1f} passes {st['passes']}")
         path3, score3, rc3 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
         fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
         with pytest.raises(decoder.FlashVitError):

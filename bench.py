@@ -303,7 +303,13 @@ def main():
     alg_bytes = 4.0 * K * (beam if is_beam else K)
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
     kname = "fvb::beam_step(+_q16) + fvb::topb_select" if is_beam else KERNEL_NAMES[st["kernel"]]
-    traffic, traffic_src = (None, None) if is_beam else load_traffic(kname)
+    if is_beam:
+        # PMC passes exist for the cfg4 workload only (tools/prof_bench.sh): bytes of an average beam_step launch
+        traffic, traffic_src = load_traffic("fvb::beam_step") if args.workload == "cfg4" else (None, None)
+        if traffic_src:
+            traffic_src += "; average fvb::beam_step launch of the cfg4 decode (single- and multi-pass launches mixed), selects not included"
+    else:
+        traffic, traffic_src = load_traffic(kname)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "achieved_is": "ALGORITHMIC GB/s (4 B per cell / step time): the SURVEY 8(d) fraction, not bytes moved",
                 "traffic": traffic, "traffic_source": traffic_src,

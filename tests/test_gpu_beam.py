@@ -96,6 +96,33 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
     fv.close()
 
 
+@pytest.mark.parametrize("kind,K,M,T,N,B,seed,prob", [("ties_semi", 7000, 4, 24, 3, 64, 231, 0.5), ("ties_all", 6500, 4, 20, 1, 40, 232, 0.5),
+                                                      ("data_script", 9000, 6, 40, 4, 100, 233, 0.01)])
+def test_beam_candidate_lists_under_ties_and_bad_predictions(kind, K, M, T, N, B, seed, prob):
+    """K >= 3 * 2048 switches the selects' candidate lists on (beam_step's epilogue collects the scores above a predicted
+    lower bound of the next cut).  Tie-heavy models give a zero beam spread and jumpy cut values (the predictor is then
+    wrong: lists too short or overflowing are ignored), a very sparse model leaves most scores at -FLT_MAX.  Every margin
+    from "no list is ever long enough" to "every list overflows" must give the oracle's bits; FV_OPT_DEBUG bit 10 turns
+    the lists off."""
+    import modelgen
+    spec = dict(kind=kind, K=K, M=M, T=T, prob=prob, seed=seed)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, N, B)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    used = 0
+    for margin, dbg in ((500, 0), (0, 0), (100000, 0), (500, 512), (500, 1024)):
+        fv.set_option(decoder.OPT_SEL_MARGIN, margin)
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        path, score, rc = fv.decode_beam(ob, N, B)
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc, (margin, dbg)
+        used += fv.stats()["beam_cand_selects"] if dbg != 1024 else 0
+        assert dbg != 1024 or fv.stats()["beam_cand_selects"] == 0
+    fv.close()
+    assert kind != "data_script" or used > 0          # the generate_data model does use its lists
+
+
 def test_beam_equal_to_K_is_full_decode():
     """B = K keeps every state: same path and score as the full-state decoder."""
     import modelgen

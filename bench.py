@@ -218,11 +218,21 @@ def main():
     model64, (A, B, Pi), ob = build_workload(w)
     gather_mode = "ncclAllGather inside libflashvit"
     dist = None
+    # FV_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share
+    # devices, tensors of the rendezvous stay on the CPU, RCCL is not used: two ranks cannot share a GPU in one
+    # communicator).  The driver's runs use the default, nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("FV_BENCH_BACKEND", "nccl")
+    tdev = "cpu"
     if "RANK" in os.environ:      # launched by torch.distributed.run (also exercised with 1 rank)
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            tdev = "cuda"
+        else:
+            dist.init_process_group(backend=backend)
+            local_rank = local_rank % max(1, torch.cuda.device_count())
 
     def new_decoder():
         d = decoder.FlashViterbi(local_rank)
@@ -236,13 +246,20 @@ def main():
         return d
 
     fv = new_decoder()
+    single_rank_path = None
+    if dist is not None and world > 1:
+        # before the context is partitioned: the whole decode on this rank alone, to check the merged result against
+        single_rank_path = (fv.decode_beam(ob, N_SPLIT, beam, decoder.MODE_REFERENCE) if is_beam
+                            else fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE))[0].tolist()
     if dist is not None:
         # torch.distributed is the rendezvous only: the 128-byte RCCL id travels over it, the data-path
         # collective (one all-gather per decode) is issued by libflashvit on its own stream
         uid = [decoder.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ok = torch.ones(1, device="cuda")
+        ok = torch.ones(1, device=tdev)
         try:
+            if backend != "nccl":
+                raise decoder.FlashVitError(-8, "rehearsal backend: RCCL communicator not created")
             fv.comm_init(rank, world, uid[0])
         except decoder.FlashVitError as e:
             print(f"[rank {rank}] fv_comm_init failed ({e}); falling back to torch.distributed all_gather", file=sys.stderr)
@@ -259,7 +276,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
 
     def decode():
         # synchronous: returns after the library's stream has drained
@@ -269,7 +287,7 @@ def main():
             path, score, rc = fv.decode_full(ob, N_SPLIT, decoder.MODE_REFERENCE)
         if dist is not None and gather_mode.startswith("torch"):
             import torch
-            mine = torch.from_numpy(path).cuda()
+            mine = torch.from_numpy(path).to(tdev)
             bufs = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(bufs, mine)
             path = decoder.merge_paths(T, N_SPLIT, world, torch.stack(bufs).cpu().numpy())
@@ -289,7 +307,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = fv.stats()
@@ -371,6 +389,7 @@ def main():
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
                        "exact_heap_replays_on_critical_path": st["beam_exact_sets"] if is_beam else None,
                        "rc": int(rc),
+                       "merged_path_equal_to_single_rank": (None if single_rank_path is None else bool(np.asarray(path).tolist() == single_rank_path)),
                        "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none",
                        "multi_gpu_status": "RCCL all-gather path unverified on hardware until a driver SCALE run exists" if args.gpus == 1 else None},
             "decode_ms": 1e3 * dt / args.steps,

@@ -1294,6 +1294,17 @@ extern "C" long long fv_checkpoint_memory_bytes(int K, int T, int step)
     return 4LL * K + 4LL * K * nck + 4LL * K + 4LL * (T / step + 1) + 8LL * K * tsub;   // :250
 }
 
+#ifdef FV_REPLAY_PROF
+// Experiment builds only: read and reset the replay profile (fv_beam_kernels.hip.inc, replay_prof).
+extern "C" int fv_debug_replay_prof(unsigned long long *out8)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fvb::replay_prof), sizeof z) != hipSuccess) return FV_ERR_DEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fvb::replay_prof), z, sizeof z) != hipSuccess) return FV_ERR_DEVICE;
+    return FV_OK;
+}
+#endif
+
 extern "C" int fv_last_stats(const fv_ctx *ctx, fv_stats *out)
 {
     if (!ctx || !out) return FV_ERR_ARG;

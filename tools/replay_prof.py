@@ -1,0 +1,31 @@
+"""Where a critical-path heap replay of FLASH-BS spends its time (experiment build with -DFV_REPLAY_PROF).
+  python tools/replay_prof.py --build          (here: compiles tools/micro/libflashvit_prof.so)
+  python tools/replay_prof.py K T N B          (on the GPU box)"""
+import os, sys, ctypes, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from flash_viterbi_amd import build as _build
+PROF_LIB = os.path.join(ROOT, "tools", "micro", "libflashvit_prof.so")
+if sys.argv[1] == "--build":
+    src = [os.path.join(_build.CSRC, s) for s in _build.HIP_SOURCES] + [os.path.join(_build.CSRC, "fv_schedule.cpp")]
+    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+           "-DFV_REPLAY_PROF", "-I", _build.INCLUDE, "-I", _build.CSRC, "-o", PROF_LIB] + src + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd); print(PROF_LIB); sys.exit(0)
+_build.HIP_LIB = PROF_LIB
+import numpy as np, modelgen
+from flash_viterbi_amd import decoder
+K, T, N, B = (int(x) for x in sys.argv[1:5])
+spec = dict(kind="sparse_fast" if K > 20000 else "data_script", K=K, M=50, T=T, prob=0.112, seed=12)
+A, Bm, Pi, ob = modelgen.model32(spec)
+fv = decoder.FlashViterbi(0); fv.set_model(A, Bm, Pi)
+L = decoder.load_library()
+out = (ctypes.c_ulonglong * 8)()
+for rep in range(2):
+    L.fv_debug_replay_prof(out)          # reset
+    p, s, rc = fv.decode_beam(ob, N, B, 0)
+    st = fv.stats()
+    L.fv_debug_replay_prof(out)
+    n = max(1, out[0]); ops = max(1, out[5])
+    print(f"K={K} T={T} N={N} B={B}: gpu_ms {st['gpu_ms']:.3f} top_ms {st['top_pass_ms']:.3f} exact_sets {st['beam_exact_sets']}; critical-path replays {out[0]}: "
+          f"per replay: init+build {out[1]/n:.0f} ticks, loop {out[2]/n:.0f}, drain {out[3]/n:.0f}; batches {out[4]/n:.1f}, ops {out[5]/n:.1f}, "
+          f"empty polls {out[6]/n:.1f}, popped {out[7]/n:.1f}; loop ticks per op {out[2]/ops:.1f} (s_memtime ticks = cycles at 2.4 GHz on this box: tools/micro/lone_wave.hip)", flush=True)

@@ -81,6 +81,8 @@ struct fv_ctx {
     DevBuf<int> d_cand_count;    // [T]
     float opt_sel_margin = 0.5f; // FV_OPT_SEL_MARGIN (in 1/1000): margin of the predicted cut bound in beam spreads
     DevBuf<int> d_dupwin;        // [T]
+    DevBuf<int> d_passL;         // first position of every pass of the generation in flight (beam decodes)
+    std::vector<int> h_passL;
     DevBuf<unsigned int> d_tie_count;
 
     // options
@@ -120,7 +122,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -632,7 +634,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -947,33 +949,32 @@ inline int beam_ldq(int K) { return (K + fvb::BEAMQ_COLS - 1) / fvb::BEAMQ_COLS 
 // by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
 // scores after consuming ob[j] (j = L: the init row), set_*[j] = the members of the heap built from
 // them (order-free), slot_*[j] = its exact array layout (rebuilt after the lock-step loop).
-int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, int T)
+int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t pass_off, int beam, int T)
 {
     const int K = ctx->K, np = (int)passes.size();
     if (np == 0) return 0;
-    std::stable_sort(passes.begin(), passes.end(),
-                     [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
-    auto scores_at = [&](int j) { return ctx->d_scores.p + (size_t)j * K; };
-    auto setv_at = [&](int j) { return ctx->d_hval.p + (size_t)j * beam; };
-    auto sets_at = [&](int j) { return ctx->d_hstate.p + (size_t)j * beam; };
     FV_HIP(hipMemsetAsync(ctx->d_tie_count.p, 0, sizeof(unsigned int), ctx->stream));
     const int cand_cap = (ctx->opt_debug & 1024) ? 0 : fvb::cand_cap_for(K, beam);     // FV_OPT_DEBUG bit 10: no candidate lists
-    auto cut_at = [&](int j) { return ctx->d_cut.p + (size_t)j * fvb::CUT_W; };
-    auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s
-        for (int base = 0; base < count; base += fvb::BEAM_CHUNK) {
-            fvb::SelArgs a;
-            a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.n = std::min(fvb::BEAM_CHUNK, count - base);
-            a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
-            for (int q = 0; q < a.n; ++q) {
-                const int j = passes[base + q].L + s;
-                a.p[q] = fvb::SelJob{ scores_at(j), setv_at(j), sets_at(j), cut_at(j), s >= 1 ? cut_at(j - 1) : nullptr,
-                                      (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
-            }
-            // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
-            fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap) : nullptr;
-            hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K), dim3(a.n), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
-            FV_HIP(hipGetLastError());
+    // passes arrive longest first; their first positions are in d_passL[pass_off ..] (decode_beam_impl)
+    fvb::BeamBase bb;
+    bb.scores_all = ctx->d_scores.p; bb.hval = ctx->d_hval.p; bb.hstate = ctx->d_hstate.p;
+    bb.cut = ctx->d_cut.p; bb.passL = ctx->d_passL.p + pass_off;
+    auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s: one launch
+        fvb::SelArgs a;
+        a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.s = s;
+        a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
+        a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.b = bb;
+        const bool listed = count <= fvb::BEAM_CHUNK;
+        for (int q = 0; listed && q < count; ++q) {
+            const int j = passes[q].L + s;
+            a.p[q] = fvb::SelJob{ ctx->d_scores.p + (size_t)j * K, ctx->d_hval.p + (size_t)j * beam, ctx->d_hstate.p + (size_t)j * beam,
+                                  ctx->d_cut.p + (size_t)j * fvb::CUT_W, s >= 1 ? ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W : nullptr,
+                                  (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
         }
+        // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
+        fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap, listed) : nullptr;
+        hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K, listed), dim3(count), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
+        FV_HIP(hipGetLastError());
         return 0;
     };
     // init scores (the same rows the full variant starts from, FLASH_BS:407-427), then the first heaps' members
@@ -1006,13 +1007,13 @@ int run_generation_beam(fv_ctx *ctx, std::vector<fv::Pass> &passes, int beam, in
             a.n = std::min(fvb::BEAM_CHUNK, active - base);
             for (int q = 0; q < a.n; ++q) {
                 const int j = passes[base + q].L + s;
-                a.p[q].sval = setv_at(j - 1);
-                a.p[q].sstate = sets_at(j - 1);
-                a.p[q].scores = scores_at(j);
+                a.p[q].sval = ctx->d_hval.p + (size_t)(j - 1) * beam;
+                a.p[q].sstate = ctx->d_hstate.p + (size_t)(j - 1) * beam;
+                a.p[q].scores = ctx->d_scores.p + (size_t)j * K;
                 a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
                 a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
                 a.p[q].j = j;
-                a.p[q].cut = cut_at(j - 1);
+                a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W;
                 a.p[q].dupwin = ctx->d_dupwin.p + j;
             }
             // The 16-bit filter kernel moves a quarter of the bytes but has two more dependent phases (window,
@@ -1142,13 +1143,26 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    // The passes of a generation run in lock-step, longest first (the active ones are a prefix); the kernels find a
+    // pass's rows from its first position, so the whole plan's pass lists go to the device once, before the clock starts.
+    std::vector<size_t> pass_off(gens.size(), 0);
+    ctx->h_passL.clear();
+    for (size_t g = 0; g < gens.size(); ++g) {
+        std::stable_sort(gens[g].begin(), gens[g].end(),
+                         [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
+        pass_off[g] = ctx->h_passL.size();
+        for (const fv::Pass &p : gens[g]) ctx->h_passL.push_back(p.L);
+    }
+    FV_HIP(ctx->d_passL.ensure(std::max<size_t>(1, ctx->h_passL.size())));
+    if (!ctx->h_passL.empty())
+        FV_HIP(hipMemcpyAsync(ctx->d_passL.p, ctx->h_passL.data(), ctx->h_passL.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     for (size_t g = 0; g < gens.size(); ++g) {
         ctx->stats.passes += (int)gens[g].size();
-        if ((rc = run_generation_beam(ctx, gens[g], beam_width, T))) return rc;
+        if ((rc = run_generation_beam(ctx, gens[g], pass_off[g], beam_width, T))) return rc;
         if (g == 0) { FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream)); FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream)); }
     }
     ctx->stats.cells = ctx->stats.task_steps * (long long)ctx->K * beam_width;

@@ -5,6 +5,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, modelgen, oracle
+from flash_viterbi_amd import build as _build
+if os.environ.get("FV_LIB"): _build.HIP_LIB = os.path.abspath(os.environ["FV_LIB"])     # A/B runs against another build of the library
 from flash_viterbi_amd import decoder
 kind = sys.argv[1]; K, T, N = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 B = int(sys.argv[5]) if kind == "beam" else 0

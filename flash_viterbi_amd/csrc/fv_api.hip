@@ -962,6 +962,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
     auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s: one launch
         fvb::SelArgs a;
         a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.s = s;
+        a.no_wave = (ctx->opt_debug & 32768) ? 1 : 0;
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
         a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.b = bb;
         const bool listed = count <= fvb::BEAM_CHUNK;

@@ -76,6 +76,31 @@ def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
     fv.close()
 
 
+@pytest.mark.parametrize("kind,K,M,T,N,B,seed,prob", [("data_script", 7000, 8, 60, 4, 64, 241, 0.05), ("ties_semi", 7000, 4, 24, 3, 64, 242, 0.5),
+                                                      ("data_script", 16500, 10, 24, 8, 300, 243, 0.02)])
+def test_beam_four_wave_select_equals_workgroup_select(kind, K, M, T, N, B, seed, prob):
+    """Candidate lists of up to 2048 entries are selected by four waves (the other twelve leave the kernel at once);
+    FV_OPT_DEBUG bit 15 keeps the whole-workgroup form.  Both must give the oracle's bits, and the same statistics
+    (selects on a list, exact replays)."""
+    import modelgen
+    spec = dict(kind=kind, K=K, M=M, T=T, prob=prob, seed=seed)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, N, B)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    seen = []
+    for dbg in (0, 32768, 512, 512 | 32768):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        path, score, rc = fv.decode_beam(ob, N, B)
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc, dbg
+        st = fv.stats()
+        seen.append((st["beam_cand_selects"], st["beam_exact_sets"]))
+    fv.close()
+    assert seen[0] == seen[1] and seen[2] == seen[3]
+    assert kind != "data_script" or seen[0][0] > 0
+
+
 @pytest.mark.parametrize("kind,K,M,T,N,B,seed", [("ties_semi", 1200, 4, 40, 4, 50, 221), ("ties_all", 600, 4, 30, 3, 33, 222),
                                                  ("ties_semi", 5000, 4, 16, 1, 200, 223)])
 def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):

@@ -5,7 +5,7 @@ import os, sys, ctypes, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from flash_viterbi_amd import build as _build
-PROF_LIB = os.path.join(ROOT, "tools", "micro", "libflashvit_prof.so")
+PROF_LIB = os.path.abspath(os.environ.get("FV_PROF_LIB", os.path.join(ROOT, "tools", "micro", "libflashvit_prof.so")))
 if sys.argv[1] == "--build":
     src = [os.path.join(_build.CSRC, s) for s in _build.HIP_SOURCES] + [os.path.join(_build.CSRC, "fv_schedule.cpp")]
     cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",

@@ -47,6 +47,11 @@ struct DevBuf {
 struct fv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // FLASH-BS: the passes of a generation are dealt to up to 1 + BEAM_AUX streams, so that the selects / exact replays
+    // of one group (a CU each) run under the step kernels of the others
+    static constexpr int BEAM_AUX = 3;
+    hipStream_t aux[BEAM_AUX] = { nullptr, nullptr, nullptr };
+    hipEvent_t ev_fork = nullptr, ev_join[BEAM_AUX] = { nullptr, nullptr, nullptr };
     int num_cus = 256;       // multiProcessorCount of the device (MI355X: 256)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     std::string detail;
@@ -569,6 +574,7 @@ int drained(fv_ctx *ctx, int rc)
         if (g) (void)hipGraphDestroy(g);
     }
     (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t a : ctx->aux) if (a) (void)hipStreamSynchronize(a);
     for (hipGraphExec_t ge : ctx->graphs) (void)hipGraphExecDestroy(ge);
     ctx->graphs.clear();
     (void)hipGetLastError();          // the failure is reported through rc / detail, not left sticky
@@ -591,6 +597,10 @@ extern "C" int fv_create(fv_ctx **out, int device)
     auto fail = [&](int rc) { fv_destroy(ctx); return rc; };
     if (hipSetDevice(device) != hipSuccess) return fail(FV_ERR_DEVICE);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(FV_ERR_DEVICE);
+    for (int q = 0; q < fv_ctx::BEAM_AUX; ++q)
+        if (hipStreamCreateWithFlags(&ctx->aux[q], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join[q], hipEventDisableTiming) != hipSuccess) return fail(FV_ERR_DEVICE);
+    if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(FV_ERR_DEVICE);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ctx->num_cus = cus;
@@ -641,6 +651,11 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     if (ctx->ev_top) (void)hipEventDestroy(ctx->ev_top);
     if (ctx->ev_s0) (void)hipEventDestroy(ctx->ev_s0);
     if (ctx->ev_s1) (void)hipEventDestroy(ctx->ev_s1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int q = 0; q < fv_ctx::BEAM_AUX; ++q) {
+        if (ctx->ev_join[q]) (void)hipEventDestroy(ctx->ev_join[q]);
+        if (ctx->aux[q]) (void)hipStreamDestroy(ctx->aux[q]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -949,36 +964,50 @@ inline int beam_ldq(int K) { return (K + fvb::BEAMQ_COLS - 1) / fvb::BEAMQ_COLS 
 // by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
 // scores after consuming ob[j] (j = L: the init row), set_*[j] = the members of the heap built from
 // them (order-free), slot_*[j] = its exact array layout (rebuilt after the lock-step loop).
+// Streams a generation of np passes is dealt to (pass i of the length-sorted list goes to group i % n).
+// Only for big steps (cfg5: 64 M cells per pass and step; FV_OPT_DEBUG bit 17 forces it): once the auxiliary queues
+// have carried work, every dispatch on the main stream takes ~2 us longer (measured, also with the main stream at
+// high priority) — 1 ms over the whole-sequence pass of cfg4, more than the overlap returns there.
+inline int beam_groups(const fv_ctx *ctx, int np, int beam)
+{
+    if ((ctx->opt_debug & 65536) || np < 2) return 1;            // FV_OPT_DEBUG bit 16: one stream
+    if (!(ctx->opt_debug & 131072) && (double)beam * ctx->K < 16e6) return 1;
+    return std::min(1 + fv_ctx::BEAM_AUX, np);
+}
+
 int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t pass_off, int beam, int T)
 {
     const int K = ctx->K, np = (int)passes.size();
     if (np == 0) return 0;
     FV_HIP(hipMemsetAsync(ctx->d_tie_count.p, 0, sizeof(unsigned int), ctx->stream));
     const int cand_cap = (ctx->opt_debug & 1024) ? 0 : fvb::cand_cap_for(K, beam);     // FV_OPT_DEBUG bit 10: no candidate lists
-    // passes arrive longest first; their first positions are in d_passL[pass_off ..] (decode_beam_impl)
+    // passes arrive group by group (decode_beam_impl), longest first inside a group; their first positions are in
+    // d_passL[pass_off ..] in the same order
     fvb::BeamBase bb;
     bb.scores_all = ctx->d_scores.p; bb.hval = ctx->d_hval.p; bb.hstate = ctx->d_hstate.p;
     bb.cut = ctx->d_cut.p; bb.passL = ctx->d_passL.p + pass_off;
-    auto select = [&](int count, int s) -> int {        // members of every active pass's heap at lock-step s: one launch
+    // members of the heaps of passes [first, first + count) at lock-step s: one launch
+    auto select = [&](int first, int count, int s, hipStream_t st) -> int {
         fvb::SelArgs a;
         a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.s = s;
         a.no_wave = (ctx->opt_debug & 32768) ? 1 : 0;
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
         a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.b = bb;
+        a.b.passL = bb.passL + first;
         const bool listed = count <= fvb::BEAM_CHUNK;
         for (int q = 0; listed && q < count; ++q) {
-            const int j = passes[q].L + s;
+            const int j = passes[first + q].L + s;
             a.p[q] = fvb::SelJob{ ctx->d_scores.p + (size_t)j * K, ctx->d_hval.p + (size_t)j * beam, ctx->d_hstate.p + (size_t)j * beam,
                                   ctx->d_cut.p + (size_t)j * fvb::CUT_W, s >= 1 ? ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W : nullptr,
                                   (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
         }
         // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
         fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap, listed) : nullptr;
-        hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K, listed), dim3(count), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), ctx->stream, a);
+        hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K, listed), dim3(count), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), st, a);
         FV_HIP(hipGetLastError());
         return 0;
     };
-    // init scores (the same rows the full variant starts from, FLASH_BS:407-427), then the first heaps' members
+    // init scores (the same rows the full variant starts from, FLASH_BS:407-427)
     for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
         fvk::PassChunk ch;
         ch.n = std::min(fvk::PASS_CHUNK, np - base);
@@ -991,49 +1020,64 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                            ctx->d_scores.p, K);
         FV_HIP(hipGetLastError());
     }
-    int rc = select(np, 0);
-    if (rc) return rc;
-    const int maxlen = passes[0].R - passes[0].L;
-    int active = np;
-    for (int s = 1; s <= maxlen; ++s) {
-        while (active > 0 && passes[active - 1].R - passes[active - 1].L < s) --active;
-        for (int base = 0; base < active; base += fvb::BEAM_CHUNK) {
-            fvb::BeamStepArgs a;
-            a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
-            a.tie_cap = (unsigned int)ctx->d_tie_list.n;
-            a.counters = ctx->d_counters.p;
-            a.K = K; a.ld = beam_ld(K); a.ldq = beam_ldq(K); a.beam = beam;
-            a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->LAQ16R.p ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
-            a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.cand_cap = cand_cap;
-            a.n = std::min(fvb::BEAM_CHUNK, active - base);
-            for (int q = 0; q < a.n; ++q) {
-                const int j = passes[base + q].L + s;
-                a.p[q].sval = ctx->d_hval.p + (size_t)(j - 1) * beam;
-                a.p[q].sstate = ctx->d_hstate.p + (size_t)(j - 1) * beam;
-                a.p[q].scores = ctx->d_scores.p + (size_t)j * K;
-                a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
-                a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
-                a.p[q].j = j;
-                a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W;
-                a.p[q].dupwin = ctx->d_dupwin.p + j;
+    // Every group runs its passes in lock-step on its own stream: first heaps' members, then step + select per position.
+    // A select launch lasts as long as its slowest exact replay and keeps one CU per pass busy; the step kernels of
+    // the other groups fill the rest of the chip meanwhile.
+    const int ng = beam_groups(ctx, np, beam);
+    if (ng > 1) FV_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    int rc = 0;
+    for (int g = 0, first = 0; g < ng; ++g) {
+        const int gn = (np - g + ng - 1) / ng;                 // passes g, g + ng, ... of the sorted list
+        hipStream_t st = g == 0 ? ctx->stream : ctx->aux[g - 1];
+        if (g > 0) FV_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        if ((rc = select(first, gn, 0, st))) return rc;
+        const int maxlen = passes[first].R - passes[first].L;
+        int active = gn;
+        for (int s = 1; s <= maxlen; ++s) {
+            while (active > 0 && passes[first + active - 1].R - passes[first + active - 1].L < s) --active;
+            for (int base = 0; base < active; base += fvb::BEAM_CHUNK) {
+                fvb::BeamStepArgs a;
+                a.LA64R = ctx->LA64R.p; a.tie_count = ctx->d_tie_count.p; a.tie_list = ctx->d_tie_list.p;
+                a.tie_cap = (unsigned int)ctx->d_tie_list.n;
+                a.counters = ctx->d_counters.p;
+                a.K = K; a.ld = beam_ld(K); a.ldq = beam_ldq(K); a.beam = beam;
+                a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->LAQ16R.p ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
+                a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.cand_cap = cand_cap;
+                a.n = std::min(fvb::BEAM_CHUNK, active - base);
+                for (int q = 0; q < a.n; ++q) {
+                    const int j = passes[first + base + q].L + s;
+                    a.p[q].sval = ctx->d_hval.p + (size_t)(j - 1) * beam;
+                    a.p[q].sstate = ctx->d_hstate.p + (size_t)(j - 1) * beam;
+                    a.p[q].scores = ctx->d_scores.p + (size_t)j * K;
+                    a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
+                    a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
+                    a.p[q].j = j;
+                    a.p[q].cut = ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W;
+                    a.p[q].dupwin = ctx->d_dupwin.p + j;
+                }
+                // The 16-bit filter kernel moves a quarter of the bytes but has two more dependent phases (window,
+                // float64 refine): measured at K = 16384, B = 256 it takes 13.7 us + 2.6 us per extra pass of the
+                // launch against 10.6 + 5.0 for the float64 kernel, so it is used from ~80 MB of float64 rows per
+                // launch on (cfg5: 537 MB per pass).  FV_OPT_DEBUG bit 8: never, bit 9: always.
+                const bool use_q16 = ctx->LAQ16R.p && !(ctx->opt_debug & 256) &&
+                                     ((ctx->opt_debug & 512) || (double)a.n * beam * K * 8.0 >= 80e6);
+                if (use_q16)
+                    hipLaunchKernelGGL(fvb::beam_step_q16, dim3(beam_ldq(K) / fvb::BEAMQ_COLS, a.n), dim3(fvb::BEAM_BLOCK),
+                                       fvb::beam_step_q16_lds(beam), st, a);
+                else
+                    hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
+                                       st, a);
+                FV_HIP(hipGetLastError());
+                ctx->stats.step_launches += 1;
+                ctx->stats.task_steps += a.n;
             }
-            // The 16-bit filter kernel moves a quarter of the bytes but has two more dependent phases (window,
-            // float64 refine): measured at K = 16384, B = 256 it takes 13.7 us + 2.6 us per extra pass of the
-            // launch against 10.6 + 5.0 for the float64 kernel, so it is used from ~80 MB of float64 rows per
-            // launch on (cfg5: 537 MB per pass).  FV_OPT_DEBUG bit 8: never, bit 9: always.
-            const bool use_q16 = ctx->LAQ16R.p && !(ctx->opt_debug & 256) &&
-                                 ((ctx->opt_debug & 512) || (double)a.n * beam * K * 8.0 >= 80e6);
-            if (use_q16)
-                hipLaunchKernelGGL(fvb::beam_step_q16, dim3(beam_ldq(K) / fvb::BEAMQ_COLS, a.n), dim3(fvb::BEAM_BLOCK),
-                                   fvb::beam_step_q16_lds(beam), ctx->stream, a);
-            else
-                hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
-                                   ctx->stream, a);
-            FV_HIP(hipGetLastError());
-            ctx->stats.step_launches += 1;
-            ctx->stats.task_steps += a.n;
+            if ((rc = select(first, active, s, st))) return rc;
         }
-        if ((rc = select(active, s))) return rc;
+        if (g > 0) {
+            FV_HIP(hipEventRecord(ctx->ev_join[g - 1], st));
+            FV_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
+        }
+        first += gn;
     }
     // off the critical path: exact layouts of every step's heap, tie fix-up, pass ends
     for (int base = 0; base < np; base += fvb::HEAP_CHUNK) {
@@ -1151,6 +1195,14 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     for (size_t g = 0; g < gens.size(); ++g) {
         std::stable_sort(gens[g].begin(), gens[g].end(),
                          [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
+        {   // group-major: the passes of stream group q (i % ng == q), longest first, then those of group q + 1
+            const int np = (int)gens[g].size(), ng = beam_groups(ctx, np, beam_width);
+            std::vector<fv::Pass> byg;
+            byg.reserve(gens[g].size());
+            for (int q = 0; q < ng; ++q)
+                for (int i = q; i < np; i += ng) byg.push_back(gens[g][i]);
+            gens[g].swap(byg);
+        }
         pass_off[g] = ctx->h_passL.size();
         for (const fv::Pass &p : gens[g]) ctx->h_passL.push_back(p.L);
     }

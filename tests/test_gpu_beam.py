@@ -101,6 +101,27 @@ def test_beam_four_wave_select_equals_workgroup_select(kind, K, M, T, N, B, seed
     assert kind != "data_script" or seen[0][0] > 0
 
 
+@pytest.mark.parametrize("kind,K,M,T,N,B,seed,prob", [("data_script", 3000, 8, 96, 8, 64, 251, 0.1), ("ties_semi", 2500, 4, 64, 16, 40, 252, 0.5),
+                                                      ("data_script", 7000, 8, 50, 5, 100, 253, 0.05)])
+def test_beam_pass_groups_on_several_streams_equal_one_stream(kind, K, M, T, N, B, seed, prob):
+    """Big steps deal the passes of a generation to four streams (the selects / replays of one group run under the step
+    kernels of the others).  FV_OPT_DEBUG bit 17 forces that for any size, bit 16 forbids it: same bits as the oracle
+    either way, N = 5 / 8 / 16 give generations of 1..64 passes (groups of unequal sizes and lengths)."""
+    import modelgen
+    spec = dict(kind=kind, K=K, M=M, T=T, prob=prob, seed=seed)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, N, B)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    for dbg in (131072, 65536, 131072 | 512, 131072 | 1024, 0):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        for rep in range(2):
+            path, score, rc = fv.decode_beam(ob, N, B)
+            assert path.tolist() == opath.tolist() and score == oscore and rc == orc, (dbg, rep)
+    fv.close()
+
+
 @pytest.mark.parametrize("kind,K,M,T,N,B,seed", [("ties_semi", 1200, 4, 40, 4, 50, 221), ("ties_all", 600, 4, 30, 3, 33, 222),
                                                  ("ties_semi", 5000, 4, 16, 1, 200, 223)])
 def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):

@@ -1215,6 +1215,11 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     for (size_t g = 0; g < gens.size(); ++g) {
         ctx->stats.passes += (int)gens[g].size();
+        // Work queued on the auxiliary streams slows every dispatch of the main one while it waits there for its fork
+        // event (the command processor keeps re-examining the blocked queues: +2 us per launch, 1 ms over the
+        // whole-sequence pass of cfg4).  The host therefore does not run ahead of a serial generation into a forked one.
+        if (g > 0 && beam_groups(ctx, (int)gens[g].size(), beam_width) > 1 && beam_groups(ctx, (int)gens[g - 1].size(), beam_width) == 1)
+            FV_HIP(hipStreamSynchronize(ctx->stream));
         if ((rc = run_generation_beam(ctx, gens[g], pass_off[g], beam_width, T))) return rc;
         if (g == 0) { FV_HIP(hipEventRecord(ctx->ev_top, ctx->stream)); FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream)); }
     }

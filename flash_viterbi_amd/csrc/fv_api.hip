@@ -52,6 +52,9 @@ struct fv_ctx {
     static constexpr int BEAM_AUX = 3;
     hipStream_t aux[BEAM_AUX] = { nullptr, nullptr, nullptr };
     hipEvent_t ev_fork = nullptr, ev_join[BEAM_AUX] = { nullptr, nullptr, nullptr };
+    bool fork_active = false;     // a forked generation of the current decode has been queued
+    hipStream_t lstream = nullptr; // stream the next full-state step launch goes to (nullptr: `stream`)
+    bool forked_batches = false;  // the launches of this generation alternate between streams: co-resident workgroups wanted
     int num_cus = 256;       // multiProcessorCount of the device (MI355X: 256)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_top = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
     std::string detail;
@@ -174,7 +177,7 @@ constexpr int U_UP = 16, U_DB32 = 4, U_DB64 = 2, U_DB16 = 2;
 template <typename TA, int NB, int U, bool DB>
 int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
 {
-    hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U, DB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->stream, a);
+    hipLaunchKernelGGL((fvk::trellis_step<TA, NB, U, DB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::BLOCK), lds, ctx->lstream ? ctx->lstream : ctx->stream, a);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -246,7 +249,7 @@ int launch_sparse_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb)
     a.window = ctx->windowq; a.qscale = ctx->qscale;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     hipLaunchKernelGGL((fvk::trellis_step_sparse<NB>), dim3(a.tiles_per_xcd * 8), dim3(fvk::SP_BLOCK),
-                       fvk::sparse_lds_bytes<NB>(ctx->nrows), ctx->stream, a);
+                       fvk::sparse_lds_bytes<NB>(ctx->nrows), ctx->lstream ? ctx->lstream : ctx->stream, a);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -263,7 +266,7 @@ template <int NB, int U, bool DB, int NWV>
 int launch_u16_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a)
 {
     const size_t lds = fvk::u16_lds_bytes<NB, NWV>(ctx->nrows);
-    hipLaunchKernelGGL((fvk::trellis_step_u16<NB, U, DB, NWV>), dim3(a.tiles_per_xcd * 8), dim3(NWV * 64), lds, ctx->stream, a);
+    hipLaunchKernelGGL((fvk::trellis_step_u16<NB, U, DB, NWV>), dim3(a.tiles_per_xcd * 8), dim3(NWV * 64), lds, ctx->lstream ? ctx->lstream : ctx->stream, a);
     FV_HIP(hipGetLastError());
     return 0;
 }
@@ -287,7 +290,9 @@ int launch_u16_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
         if (a.ntiles <= ctx->num_cus && (nq + 15) / 16 <= 8 && !(ctx->opt_debug & 4)) return launch_u16_variant<NB, 8, false, 16>(ctx, a);
         return launch_u16_variant<NB, U_DB16, true, 16>(ctx, a);
     }
-    if (a.ntiles <= ctx->num_cus && (nq + 7) / 8 <= 16 && !(ctx->opt_debug & 4)) return launch_u16_variant<NB, 16, false, 8>(ctx, a);
+    // (forked batches: the double-buffered form, 81 VGPRs at NB = 4 — three 8-wave workgroups of three streams share a CU;
+    // the whole-tile form's 137 would leave room for one)
+    if (a.ntiles <= ctx->num_cus && (nq + 7) / 8 <= 16 && !(ctx->opt_debug & 4) && !ctx->forked_batches) return launch_u16_variant<NB, 16, false, 8>(ctx, a);
     return launch_u16_variant<NB, U_DB16, true, 8>(ctx, a);
 }
 
@@ -308,7 +313,7 @@ int launch_step_kernel(fv_ctx *ctx, int kernel, const fvk::TaskSlot *slots, int 
         // 10.4 vs 14.2 at T=4096 where its window is the narrower one) and for models whose float32 rows do not fit
         // LDS; the f32 filter for batched launches, where the 16-bit kernel's per-task prologue (row maximum,
         // quantisation) costs what its cheaper sweep saves.  FV_OPT_DEBUG bit 14: packed 16-bit for every launch.
-        if (nb <= 1 || !ctx->full_ok || (ctx->opt_debug & 16384)) return launch_u16(ctx, slots, nb, reverse);
+        if (nb <= 1 || !ctx->full_ok || (ctx->opt_debug & 16384) || ctx->forked_batches) return launch_u16(ctx, slots, nb, reverse);
         return launch_step<fvk::q16_t>(ctx, slots, nb, reverse);
     case FV_KERNEL_SPARSE_Q16: return launch_sparse(ctx, slots, nb);
     case FV_KERNEL_F64_STREAM: return launch_step<double>(ctx, slots, nb, reverse);
@@ -412,8 +417,36 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         FV_HIP(hipGetLastError());
     }
     const int maxlen = passes[0].R - passes[0].L;
-    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows, !ctx->full_ok)));
+    int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows, !ctx->full_ok)));
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
+    // The batches of a lock-step are independent, and a step launch is latency-bound at both ends (staging the score
+    // rows; reductions and refine): the right-hand generations of the packed 16-bit kernel therefore run as batches of
+    // FORK_CAP tasks dealt to FORK_STREAMS streams, small enough (36 KB of LDS, 81 VGPRs, 8 waves) for three workgroups
+    // of different launches to share a CU — one launch's head and tail run under the sweeps of the others.  cfg2
+    // right-hand passes 2.10 -> 1.85 ms, cfg3 62.7 -> 44.7 ms; the f32 filter in two co-resident 8-wave workgroups gave
+    // 1.96 / 53.0, batches of two tasks and four streams were slower.  FV_OPT_DEBUG bit 18: off.
+    constexpr int FORK_STREAMS = 3, FORK_CAP = 4;
+    const bool two = kernel == FV_KERNEL_U16_REFINE && ctx->u16_ok && !(ctx->opt_debug & 262144) && !whole_gen && np > FORK_CAP &&
+                     !ctx->opt_profile && !(ctx->opt_debug & 64);
+    const int nbatches = (np + FORK_CAP - 1) / FORK_CAP;
+    const int nstreams = two ? (nbatches >= 2 * FORK_STREAMS ? FORK_STREAMS : 2) : 1;     // a third stream pays from six batches on
+    if (two) {
+        cap = std::min(cap, FORK_CAP);
+        // no packets may wait on the other queues while a serial generation runs (decode_beam_impl has the measurement)
+        if (!ctx->fork_active) FV_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->fork_active = true;
+        FV_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int q = 1; q < nstreams; ++q) FV_HIP(hipStreamWaitEvent(ctx->aux[q - 1], ctx->ev_fork, 0));
+    }
+    ctx->forked_batches = two;
+    struct Unfork { fv_ctx *c; ~Unfork() { c->forked_batches = false; c->lstream = nullptr; } } unfork{ ctx };
+    auto join = [&]() -> int {
+        for (int q = 1; q < nstreams; ++q) {
+            FV_HIP(hipEventRecord(ctx->ev_join[q - 1], ctx->aux[q - 1]));
+            FV_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join[q - 1], 0));
+        }
+        return 0;
+    };
     const bool col_last = !(ctx->opt_debug & 8);  // FV_OPT_DEBUG bit 3: run every last step as a full step
     // FV_OPT_DEBUG bit 6 (experiment): capture this generation's step launches into a hipGraph and replay it
     const bool use_graph = (ctx->opt_debug & 64) && !ctx->opt_profile;
@@ -445,11 +478,18 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                 nprof += 2;
                 FV_HIP(hipEventRecord(e0, ctx->stream));
             }
+            const int other = two ? (base / cap) % nstreams : 0;         // batch b keeps its stream for the whole generation
+            ctx->lstream = other ? ctx->aux[other - 1] : ctx->stream;
             int rc = launch_step_kernel(ctx, kernel, slots, nb, s & 1);
+            ctx->lstream = nullptr;
             if (rc) return rc;
             if (ctx->opt_profile) FV_HIP(hipEventRecord(e1, ctx->stream));
             ctx->stats.step_launches += 1;
             ctx->stats.task_steps += nb;
+        }
+        if (two && full < active) {      // the single-column last steps read rows every stream has written; the finished
+            int rc = join();              // passes are the tail of the list, so the batches that go on keep their streams
+            if (rc) return rc;
         }
         for (int base = full; base < active; base += fvk::COL_CHUNK) {
             fvk::ColArgs c;
@@ -476,6 +516,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         (void)hipGraphDestroy(g);
     }
     if (whole_gen) FV_HIP(hipEventRecord(ctx->ev_s1, ctx->stream));
+    if (two) { int rc = join(); if (rc) return rc; }
     // end states + chains
     for (int q = 0; q < np; ++q) {
         if (!passes[q].whole) continue;
@@ -943,6 +984,7 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     size_t nprof = 0;
+    ctx->fork_active = false;
     for (size_t g = 0; g < gens.size(); ++g) {
         ctx->stats.passes += (int)gens[g].size();
         if ((rc = run_generation_full(ctx, gens[g], kernel, nprof))) return rc;

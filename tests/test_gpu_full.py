@@ -49,11 +49,13 @@ def test_reference_mode_matches_golden(ctxs, g, r, kernel):
 
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_packed_u16_filter_for_batched_launches_matches_golden(ctxs, g, r):
-    """FV_KERNEL_U16_REFINE uses the packed 16-bit filter for single-task launches only; FV_OPT_DEBUG bit 14 forces
-    it for the batched (right-hand) launches too, bit 13 selects its 16-wave workgroup form."""
+    """FV_KERNEL_U16_REFINE runs generations of more than four right-hand passes as batches of four on three streams
+    with the packed 16-bit filter (co-resident workgroups of different launches), everything else batched with the
+    f32 filter; FV_OPT_DEBUG bit 18 turns the streams off, bit 14 forces the packed filter for every batched launch,
+    bit 13 selects its 16-wave workgroup form.  (The default form is what every KERNEL_U16_REFINE / AUTO test runs.)"""
     fv, ob = ctxs(g)
     fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_U16_REFINE)
-    for dbg in (16384, 16384 | 8192, 16384 | 4):
+    for dbg in (262144, 262144 | 16384, 16384, 16384 | 8192, 16384 | 4, 262144 | 16384 | 8192):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         try:
             path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)

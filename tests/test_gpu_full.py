@@ -62,6 +62,14 @@ def test_packed_u16_filter_for_batched_launches_matches_golden(ctxs, g, r):
         finally:
             fv.set_option(decoder.OPT_DEBUG, 0)
         assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+    # the sparse walk forks its right-hand generations the same way: bit 18 is its single-stream form
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_SPARSE_Q16)
+    fv.set_option(decoder.OPT_DEBUG, 262144)
+    try:
+        path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)
+    finally:
+        fv.set_option(decoder.OPT_DEBUG, 0)
+    assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
 
 
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)

@@ -425,9 +425,10 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     // of different launches to share a CU — one launch's head and tail run under the sweeps of the others.  cfg2
     // right-hand passes 2.10 -> 1.85 ms, cfg3 62.7 -> 44.7 ms; the f32 filter in two co-resident 8-wave workgroups gave
     // 1.96 / 53.0, batches of two tasks and four streams were slower.  The sparse walk gains the same way (cfg3 right-hand
-    // 33.4 -> 23.1 ms, cfg2 unchanged).  FV_OPT_DEBUG bit 18: off.
+    // 33.4 -> 23.1 ms; at cfg2's 31-step passes nothing, so short generations stay on one stream and the host keeps
+    // running ahead).  FV_OPT_DEBUG bit 18: off.
     constexpr int FORK_STREAMS = 3, FORK_CAP = 4;
-    const bool two = ((kernel == FV_KERNEL_U16_REFINE && ctx->u16_ok) || kernel == FV_KERNEL_SPARSE_Q16) &&
+    const bool two = ((kernel == FV_KERNEL_U16_REFINE && ctx->u16_ok) || (kernel == FV_KERNEL_SPARSE_Q16 && maxlen >= 64)) &&
                      !(ctx->opt_debug & 262144) && !whole_gen && np > FORK_CAP &&
                      !ctx->opt_profile && !(ctx->opt_debug & 64);
     const int nbatches = (np + FORK_CAP - 1) / FORK_CAP;

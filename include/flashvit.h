@@ -57,7 +57,15 @@ enum {
     FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
     FV_OPT_SEL_MARGIN = 4,  /* FLASH-BS: margin, in 1/1000 of the beam spread (max - cut value), below the extrapolated cut value
                                from which the step kernels collect the next select's candidates (default 500); speed only */
-    FV_OPT_DEBUG = 100,     /* kernel-tuning switches for timing experiments only (bit0 voids results) */
+    FV_OPT_DEBUG = 100,     /* kernel-tuning switches (a bit mask) for timing experiments and for the parity tests, which run
+                               every alternative form of a kernel against the same goldens.  Only bits 0, 4, 11 and 12 change
+                               results (timing-only builds).  Full-state: 0 no refine, 1 no reverse sweep, 2 alternate load
+                               schedule, 3 full last step instead of one column, 4 launch-only, 5 no score-row staging,
+                               6 hipGraph replay of a generation, 11 / 12 packed kernel without sweep / refine, 13 packed
+                               kernel in 16-wave workgroups, 14 packed kernel for every batched launch, 18 right-hand
+                               generations on one stream.  FLASH-BS: 8 / 9 float64 / 16-bit step kernel always, 10 no
+                               candidate lists, 15 whole-workgroup select for short lists too, 16 / 17 pass groups on one
+                               stream / on four streams whatever the size */
 };
 enum {
     FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else U16_REFINE;

@@ -89,6 +89,7 @@ struct fv_ctx {
     DevBuf<int> d_cand_count;    // [T]
     float opt_sel_margin = 0.5f; // FV_OPT_SEL_MARGIN (in 1/1000): margin of the predicted cut bound in beam spreads
     DevBuf<int> d_dupwin;        // [T]
+    DevBuf<int> d_needfull;      // [1] a pass's back-track met a tied cell: rebuild the layouts of the generation (beam_end_backtrack)
     DevBuf<int> d_passL;         // first position of every pass of the generation in flight (beam decodes)
     std::vector<int> h_passL;
     DevBuf<unsigned int> d_tie_count;
@@ -130,7 +131,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes() + c->d_needfull.bytes();
 }
 
 // log() of a strided block of floats on several host threads (same libm call per entry as the reference).
@@ -688,7 +689,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release(); ctx->d_needfull.release();
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -1124,37 +1125,61 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
         }
         first += gn;
     }
-    // off the critical path: exact layouts of every step's heap, tie fix-up, pass ends
-    for (int base = 0; base < np; base += fvb::HEAP_CHUNK) {
-        fvb::HeapAllArgs h;
-        h.scores_all = ctx->d_scores.p; h.slot_val = ctx->d_slot_val.p; h.slot_state = ctx->d_slot_state.p;
-        h.err_counter = ctx->d_counters.p + 5;
-        h.K = K; h.beam = beam; h.n = std::min(fvb::HEAP_CHUNK, np - base);
-        int longest = 0;
-        for (int q = 0; q < h.n; ++q) {
-            h.p[q] = fvb::HeapRange{ passes[base + q].L, passes[base + q].R };
-            longest = std::max(longest, passes[base + q].R - passes[base + q].L + 1);
+    // Pass ends.  First attempt on the provisional back-pointers (beam_end_backtrack); only the whole-sequence pass
+    // needs a layout for that — its last heap's.  The exact layouts of every step's heap and the tie fix-up are queued
+    // behind it but run only if the walk met a tied cell (FV_OPT_DEBUG bit 19: always).
+    const bool lazy = !(ctx->opt_debug & 524288);
+    FV_HIP(hipMemsetAsync(ctx->d_needfull.p, 0, sizeof(int), ctx->stream));
+    auto layouts = [&](bool last_only, const int *gate) -> int {
+        for (int base = 0; base < np; base += fvb::HEAP_CHUNK) {
+            fvb::HeapAllArgs h;
+            h.scores_all = ctx->d_scores.p; h.slot_val = ctx->d_slot_val.p; h.slot_state = ctx->d_slot_state.p;
+            h.err_counter = ctx->d_counters.p + 5; h.gate = gate;
+            h.K = K; h.beam = beam; h.n = 0;
+            int longest = 0;
+            for (int q = 0; q < std::min(fvb::HEAP_CHUNK, np - base); ++q) {
+                const fv::Pass &p = passes[base + q];
+                if (last_only && !p.whole) continue;
+                h.p[h.n++] = fvb::HeapRange{ last_only ? p.R : p.L, p.R };
+                longest = std::max(longest, last_only ? 1 : p.R - p.L + 1);
+            }
+            if (h.n == 0) continue;
+            hipLaunchKernelGGL(fvb::heap_build_all, dim3(longest, h.n), dim3(128), fvb::heap_lds(beam), ctx->stream, h);
+            FV_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(fvb::heap_build_all, dim3(longest, h.n), dim3(128), fvb::heap_lds(beam), ctx->stream, h);
-        FV_HIP(hipGetLastError());
+        return 0;
+    };
+    auto ends = [&](int lazy_walk) -> int {
+        for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
+            fvb::BeamEndArgs e;
+            e.K = K; e.beam = beam; e.n = std::min(fvb::BEAM_CHUNK, np - base);
+            e.lazy = lazy_walk; e.flag = ctx->d_needfull.p;
+            for (int q = 0; q < e.n; ++q) e.p[q] = fvb::BeamEnd{ passes[base + q].L, passes[base + q].R, passes[base + q].whole ? 1 : 0 };
+            hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_slot_val.p,
+                               ctx->d_slot_state.p, ctx->d_hstate.p, ctx->d_bp.p, ctx->d_ans.p, ctx->d_score.p);
+            FV_HIP(hipGetLastError());
+        }
+        return 0;
+    };
+    if (lazy) {
+        if ((rc = layouts(true, nullptr))) return rc;
+        if ((rc = ends(1))) return rc;
+    } else {
+        int one = 1;
+        FV_HIP(hipMemcpyAsync(ctx->d_needfull.p, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        FV_HIP(hipStreamSynchronize(ctx->stream));       // (`one` is a local; this is the experiment path)
     }
+    if ((rc = layouts(false, ctx->d_needfull.p))) return rc;
     {
         fvb::FixArgs f;
         f.LA64R = ctx->LA64R.p; f.LB32T = ctx->LB32T.p; f.ob = ctx->d_ob.p;
         f.tie_count = ctx->d_tie_count.p; f.tie_list = ctx->d_tie_list.p; f.tie_cap = (unsigned int)ctx->d_tie_list.n;
         f.slot_val = ctx->d_slot_val.p; f.slot_state = ctx->d_slot_state.p; f.bp = ctx->d_bp.p;
-        f.K = K; f.ld = beam_ld(K); f.beam = beam; f.total = ctx->d_counters.p + 6;
+        f.K = K; f.ld = beam_ld(K); f.beam = beam; f.total = ctx->d_counters.p + 6; f.gate = ctx->d_needfull.p;
         hipLaunchKernelGGL(fvb::tie_fixup, dim3(512), dim3(256), 0, ctx->stream, f);
         FV_HIP(hipGetLastError());
     }
-    for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
-        fvb::BeamEndArgs e;
-        e.K = K; e.beam = beam; e.n = std::min(fvb::BEAM_CHUNK, np - base);
-        for (int q = 0; q < e.n; ++q) e.p[q] = fvb::BeamEnd{ passes[base + q].L, passes[base + q].R, passes[base + q].whole ? 1 : 0 };
-        hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_slot_val.p,
-                           ctx->d_slot_state.p, ctx->d_bp.p, ctx->d_ans.p, ctx->d_score.p);
-        FV_HIP(hipGetLastError());
-    }
+    if ((rc = ends(0))) return rc;
     (void)T;
     return 0;
 }
@@ -1203,6 +1228,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(hipMemsetAsync(ctx->d_cand_count.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (const int cap = fvb::cand_cap_for(ctx->K, beam_width)) FV_HIP(ctx->d_cand.ensure((size_t)T * cap));
     FV_HIP(ctx->d_dupwin.ensure(T));
+    FV_HIP(ctx->d_needfull.ensure(4));
     FV_HIP(hipMemsetAsync(ctx->d_dupwin.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (!ctx->LA64R.p) {
         const int ld = beam_ld(ctx->K);

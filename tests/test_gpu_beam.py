@@ -114,7 +114,7 @@ def test_beam_pass_groups_on_several_streams_equal_one_stream(kind, K, M, T, N, 
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (131072, 65536, 131072 | 512, 131072 | 1024, 0):
+    for dbg in (131072, 65536, 131072 | 512, 131072 | 1024, 0, 524288, 131072 | 524288):     # bit 19: every layout rebuilt, always
         fv.set_option(decoder.OPT_DEBUG, dbg)
         for rep in range(2):
             path, score, rc = fv.decode_beam(ob, N, B)
@@ -134,7 +134,7 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (0, 512):
+    for dbg in (0, 512, 524288):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
         assert path.tolist() == opath.tolist() and score == oscore and rc == orc

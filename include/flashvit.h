@@ -65,7 +65,8 @@ enum {
                                kernel in 16-wave workgroups, 14 packed kernel for every batched launch, 18 right-hand
                                generations on one stream.  FLASH-BS: 8 / 9 float64 / 16-bit step kernel always, 10 no
                                candidate lists, 15 whole-workgroup select for short lists too, 16 / 17 pass groups on one
-                               stream / on four streams whatever the size */
+                               stream / on four streams whatever the size, 19 every heap layout rebuilt and every tie re-decided whether or not
+                               the path needs it */
 };
 enum {
     FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else U16_REFINE;

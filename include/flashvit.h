@@ -106,7 +106,8 @@ typedef struct {
     long long refine_near;    /* filter kernels: candidates inside the window besides a column's best */
     long long refine_rescan;  /* filter kernels: lanes that had to rescan their rows */
     long long beam_exact_sets;/* FLASH-BS: steps whose heap members needed the exact replay (duplicate scores at the cut) */
-    long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order */
+    long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order; 0 unless a back-tracked path met a cell
+                                 whose maximum two beam entries attained (only then are the heap layouts rebuilt) */
     long long beam_dup_cols;  /* FLASH-BS statistics: columns won by an entry whose value equals a duplicated cut value */
     long long beam_dup_steps; /* ... and the number of steps in which that happened at least once */
     long long beam_cand_selects; /* FLASH-BS: top-B selections that ran on a step's candidate list instead of all K scores */

@@ -382,7 +382,7 @@ def main():
                                           else "data_script.make_model32_fast (same distributions, vectorised random stream)",
                        "kernel": ("beam_step / beam_step_q16 by launch size" if is_beam else
                                   {1: "f64_stream", 2: "f32_refine", 3: "f16_refine", 4: "q16_refine", 5: "sparse_q16",
-                                   6: "u16_refine (packed 16-bit filter on single-task launches, f32 filter on batched ones; same 16-bit table)"}[st["kernel"]]),
+                                   6: "u16_refine (packed 16-bit filter: single-task launches of the whole-sequence pass; right-hand generations as batches of four on up to three streams; f32 filter for generations of <= 4 passes; same 16-bit table)"}[st["kernel"]]),
                        "kernel_note": (None if is_beam else "dense K*K sweep forced for value/roofline; the library's AUTO choice for this "
                                        "model is the sparse walk, reported separately as sparse_walk"),
                        "transition_density": st["density"] if not is_beam else None,

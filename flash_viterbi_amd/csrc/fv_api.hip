@@ -123,6 +123,8 @@ namespace {
         }                                                                                     \
     } while (0)
 
+constexpr int FV_NCOUNTERS = 16;   // device statistics words (fv_kernels.hip.inc / fv_beam_kernels.hip.inc say which is which)
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t device_bytes(const fv_ctx *c)
@@ -377,7 +379,7 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
         }
     }
     FV_HIP(ctx->d_score.ensure(4));
-    FV_HIP(ctx->d_counters.ensure(8));
+    FV_HIP(ctx->d_counters.ensure(FV_NCOUNTERS));
     if (ctx->comm) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
     return 0;
 }
@@ -570,7 +572,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
         FV_HIP(hipMemcpyAsync(path_out, ctx->d_ans.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     float score = 0.f;
-    unsigned long long counters[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long counters[FV_NCOUNTERS] = {};
     FV_HIP(hipMemcpyAsync(&score, ctx->d_score.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipMemcpyAsync(counters, ctx->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipStreamSynchronize(ctx->stream));
@@ -597,6 +599,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.beam_dup_steps = (long long)counters[4];
     st.beam_ties = (long long)counters[6];
     st.beam_cand_selects = (long long)counters[7];
+    st.refine_saturated = (long long)counters[8];
     if (counters[5]) { ctx->detail = "heap replay: producer/consumer hand-shake timed out"; return FV_ERR_DEVICE; }
     st.device_bytes = (long long)device_bytes(ctx);
     st.ranks = ctx->nranks;
@@ -984,7 +987,7 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
 
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     size_t nprof = 0;
@@ -1280,7 +1283,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(ctx->d_passL.ensure(std::max<size_t>(1, ctx->h_passL.size())));
     if (!ctx->h_passL.empty())
         FV_HIP(hipMemcpyAsync(ctx->d_passL.p, ctx->h_passL.data(), ctx->h_passL.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
@@ -1354,7 +1357,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
     ctx->stats.density = ctx->density;
     ctx->h_ob.assign(ob, ob + T);
     FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
     FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
 

@@ -116,6 +116,8 @@ typedef struct {
     int generations;          /* dependent batches of passes */
     int kernel;               /* FV_KERNEL_* actually used */
     int ranks;                /* ranks sharing the decode (1 without fv_comm_init) */
+    long long refine_saturated; /* packed 16-bit filter: (step, column) pairs whose window reached the end of the code range, so that
+                                   every source row was re-evaluated exactly (score rows spread wider than max|log A|) */
 } fv_stats;
 
 /* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role

@@ -56,7 +56,10 @@ CASES = [
 ]
 BIG_CASES = [
     dict(name="cfg2_K3965_T256", spec=dict(kind="data_script", K=3965, M=50, T=256, prob=0.112, seed=12, ob=OB_CFG2),
-         runs=F(8) + BS((8, 32), (8, 256)) + V + C(0)),
+         runs=F(8) + BS((8, 32), (8, 256)) + V + C(0) + F(1) + BS((1, 32))),
+    # the reference driver's own second parameter set (src/run.py:17-24: prob 0.169; MAX_THREADS 1, BeamSearchWidth 32)
+    dict(name="cfg2b_K3965_T256_p0169", spec=dict(kind="data_script", K=3965, M=50, T=256, prob=0.169, seed=12, ob=OB_CFG2),
+         runs=F(8, 1) + BS((8, 32), (1, 32))),
 ]
 
 

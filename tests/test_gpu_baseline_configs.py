@@ -79,7 +79,7 @@ def test_cfg3_full_decode_equals_oracle():
     try:
         fv.set_model(A, Bm, Pi)
         got = {}
-        for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_AUTO):
+        for kernel in (decoder.KERNEL_Q16_REFINE, decoder.KERNEL_U16_REFINE, decoder.KERNEL_AUTO):      # U16: what bench.py --workload cfg3 times
             fv.set_option(decoder.OPT_KERNEL, kernel)
             got[kernel] = fv.decode_full(ob, 8, decoder.MODE_REFERENCE)
             _log(f"cfg3 kernel {fv.stats()['kernel']}: gpu_ms {fv.stats()['gpu_ms']:.1f}")

@@ -138,7 +138,27 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
         assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+        if dbg == 0 and kind == "ties_all":
+            # default mode: the first back-track met a tagged cell, so the gated heap_build_all / tie_fixup / second
+            # walk did run (the branch must not ship untested)
+            assert fv.stats()["beam_ties"] > 0
     assert fv.stats()["beam_exact_sets"] > 0
+    fv.close()
+
+
+def test_beam_tie_gate_stays_shut_on_a_tie_free_model():
+    """The other side of the gate: a generate_data model whose back-tracked paths meet no tied cell never rebuilds
+    the layouts (beam_ties counts the cells tie_fixup re-decided: none)."""
+    import modelgen
+    spec = dict(kind="data_script", K=700, M=9, T=40, prob=0.2, seed=261)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, 4, 60)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    path, score, rc = fv.decode_beam(ob, 4, 60)
+    assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+    assert fv.stats()["beam_ties"] == 0
     fv.close()
 
 

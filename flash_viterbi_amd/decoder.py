@@ -16,6 +16,7 @@ MODE_SINGLE_PASS = 1
 KERNEL_AUTO, KERNEL_F64_STREAM, KERNEL_F32_REFINE, KERNEL_F16_REFINE, KERNEL_Q16_REFINE, KERNEL_SPARSE_Q16 = 0, 1, 2, 3, 4, 5
 KERNEL_U16_REFINE = 6
 OPT_KERNEL, OPT_MAX_BATCH, OPT_PROFILE, OPT_SEL_MARGIN, OPT_DEBUG = 1, 2, 3, 4, 100
+DEBUG_TIMING_ONLY = (1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12)      # refused by the shipped library
 WARN_BEAM_MISS = 1
 UNIQUE_ID_BYTES = 128
 
@@ -46,7 +47,8 @@ class PassInfo(ctypes.Structure):
 EXPORTS = ["fv_create", "fv_destroy", "fv_set_model", "fv_set_option", "fv_decode_full", "fv_decode_beam",
            "fv_decode_vanilla", "fv_decode_checkpoint", "fv_checkpoint_memory_bytes",
            "fv_last_stats", "fv_strerror", "fv_last_error_detail", "fv_reference_memory_bytes",
-           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths", "fv_set_partition"]
+           "fv_comm_unique_id", "fv_comm_init", "fv_plan_passes", "fv_merge_paths", "fv_set_partition",
+           "fv_create_multi", "fv_device_count"]
 
 _lib = None
 
@@ -56,13 +58,16 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.HIP_LIB
+    # FLASHVIT_TIMING_BUILD=1 (tools/ only): the build that keeps the result-changing timing switches of FV_OPT_DEBUG
+    path = _build.HIP_TIMING_LIB if os.environ.get("FLASHVIT_TIMING_BUILD") == "1" else _build.HIP_LIB
     if not os.path.isfile(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     L = ctypes.CDLL(path)
     vp, ci, cll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
     L.fv_create.argtypes = [ctypes.POINTER(vp), ci]
+    L.fv_create_multi.argtypes = [ctypes.POINTER(vp), vp, ci]
+    L.fv_device_count.argtypes = []
     L.fv_destroy.argtypes = [vp]
     L.fv_destroy.restype = None
     L.fv_set_model.argtypes = [vp, vp, vp, vp, ci, ci]
@@ -134,9 +139,15 @@ class FlashViterbi:
     create_vit() -> calc() -> printAns() becomes set_model() -> decode_*() -> returned path."""
 
     def __init__(self, device=0):
+        """device: one device id, or a list of ids for a single-process multi-device context (fv_create_multi;
+        an id may repeat: the members then share that GPU and gather by device-to-device copies)."""
         self._L = load_library()
         h = ctypes.c_void_p()
-        rc = self._L.fv_create(ctypes.byref(h), device)
+        if isinstance(device, (list, tuple)):
+            devs = np.ascontiguousarray(device, dtype=np.int32)
+            rc = self._L.fv_create_multi(ctypes.byref(h), _p(devs), devs.size)
+        else:
+            rc = self._L.fv_create(ctypes.byref(h), device)
         if rc != 0:
             raise FlashVitError(rc, "fv_create (is a GPU visible? there is no CPU fallback)")
         self._h = h
@@ -206,6 +217,10 @@ class FlashViterbi:
     def comm_init(self, rank, nranks, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._check(self._L.fv_comm_init(self._h, rank, nranks, buf))
+
+
+def device_count():
+    return int(load_library().fv_device_count())
 
 
 def comm_unique_id():

@@ -86,9 +86,16 @@ int main(void)
     int rc = fvh_read_ints_text(name, ob, T);
     if (rc) { fprintf(stderr, "%s: %s\n", name, fvh_strerror(rc)); return 2; }
 
+    /* FV_NGPUS devices of this one process take the place of the reference's MAX_THREADS workers (:316-335):
+     * devices FV_DEVICE, FV_DEVICE + 1, ... modulo the number of visible GPUs (so FV_NGPUS may exceed it: the members
+     * then share GPUs and the merge uses device-to-device copies instead of RCCL) */
     fv_ctx *ctx = NULL;
-    rc = fv_create(&ctx, env_int("FV_DEVICE", 0));
-    if (rc) { fprintf(stderr, "fv_create: %s\n", fv_strerror(rc)); return 3; }
+    int ngpus = env_int("FV_NGPUS", 1), devices[64];
+    const int visible = fv_device_count();
+    if (ngpus < 1 || ngpus > 64 || visible < 1) { fprintf(stderr, "FV_NGPUS=%d with %d visible GPU(s)\n", ngpus, visible); return 3; }
+    for (int i = 0; i < ngpus; ++i) devices[i] = (env_int("FV_DEVICE", 0) + i) % visible;
+    rc = fv_create_multi(&ctx, devices, ngpus);
+    if (rc) { fprintf(stderr, "fv_create_multi: %s\n", fv_strerror(rc)); return 3; }
     fv_set_option(ctx, FV_OPT_KERNEL, env_int("FV_KERNEL", FV_KERNEL_AUTO));
     const int include_model = env_int("FV_TIME_INCLUDES_MODEL", 0);
 

@@ -79,6 +79,8 @@ def run_c(filename, p):
     # raw float32 caches next to the text files: safe by default because a cache is bound to the size and mtime
     # of the text it was parsed from (include/flashvit_host.h, fvh_read_bin_src) and re-made when they differ
     env = dict(os.environ, FV_BIN_CACHE=os.environ.get("FV_BIN_CACHE", "1"))
+    if "--gpus" in sys.argv:     # devices of the one host process (FV_NGPUS, fv_create_multi); the n_gpus column reports it
+        env["FV_NGPUS"] = sys.argv[sys.argv.index("--gpus") + 1]
     res = subprocess.run([modified], capture_output=True, text=True, env=env)
     if res.returncode != 0:
         raise RuntimeError(f"run ERROR ({res.returncode}): {res.stderr}")
@@ -115,6 +117,18 @@ def main():
     for filename in file_names:
         csv_name = result_path + filename + "_result.csv"
         new = not os.path.exists(csv_name)
+        if not new:
+            # a results file written under another column layout is set aside, never appended to (its rows would sit
+            # under the wrong header)
+            with open(csv_name, encoding="utf-8", newline="") as fh:
+                first = fh.readline().rstrip("\r\n")
+            if first != ",".join(CSV_HEADER):
+                n = 1
+                while os.path.exists(f"{csv_name[:-4]}.v{n}.csv"):
+                    n += 1
+                os.rename(csv_name, f"{csv_name[:-4]}.v{n}.csv")
+                print(f"{csv_name}: header differs from this version's; kept as {csv_name[:-4]}.v{n}.csv", file=sys.stderr)
+                new = True
         with open(csv_name, "a", encoding="utf-8", newline="") as fh:
             w = csv.writer(fh)
             if new:

@@ -57,17 +57,20 @@ enum {
     FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
     FV_OPT_SEL_MARGIN = 4,  /* FLASH-BS: margin, in 1/1000 of the beam spread (max - cut value), below the extrapolated cut value
                                from which the step kernels collect the next select's candidates (default 500); speed only */
-    FV_OPT_DEBUG = 100,     /* kernel-tuning switches (a bit mask) for timing experiments and for the parity tests, which run
-                               every alternative form of a kernel against the same goldens.  Only bits 0, 4, 11 and 12 change
-                               results (timing-only builds).  Full-state: 0 no refine, 1 no reverse sweep, 2 alternate load
-                               schedule, 3 full last step instead of one column, 4 launch-only, 5 no score-row staging,
-                               6 hipGraph replay of a generation, 11 / 12 packed kernel without sweep / refine, 13 packed
-                               kernel in 16-wave workgroups, 14 packed kernel for every batched launch, 18 right-hand
-                               generations on one stream.  FLASH-BS: 8 / 9 float64 / 16-bit step kernel always, 10 no
-                               candidate lists, 15 whole-workgroup select for short lists too, 16 / 17 pass groups on one
-                               stream / on four streams whatever the size, 19 every heap layout rebuilt and every tie re-decided whether or not
-                               the path needs it */
+    FV_OPT_DEBUG = 100,     /* UNSTABLE: kernel-tuning switches (a bit mask) that select alternative forms of a kernel or of the
+                               launch schedule.  Every bit the library accepts is speed-only — the parity tests run each
+                               alternative against the same goldens (tests/test_boundary.py checks that no accepted value
+                               changes a result).  The switches that leave a part of a kernel out to time the rest (bits 0, 4, 5,
+                               11, 12 = FV_DEBUG_TIMING_ONLY) change results; they exist only in the separate timing build
+                               (libflashvit_timing.so, used by tools/), and this library answers FV_ERR_ARG to them.
+                               Full-state: 1 no reverse sweep, 2 alternate load schedule, 3 full last step instead of one
+                               column, 6 hipGraph replay of a generation, 13 packed kernel in 16-wave workgroups, 14 packed
+                               kernel for every batched launch, 18 right-hand generations on one stream.  FLASH-BS: 8 / 9
+                               float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
+                               lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
+                               layout rebuilt and every tie re-decided whether or not the path needs it */
 };
+#define FV_DEBUG_TIMING_ONLY ((1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12))
 enum {
     FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else U16_REFINE;
                                   otherwise F64_STREAM */
@@ -124,6 +127,18 @@ typedef struct {
  * (FLASH:97-107) and the ThreadPool globals (:36-46). */
 int fv_create(fv_ctx **out, int device);
 void fv_destroy(fv_ctx *ctx);
+
+/* One host process, several GPUs: the reference is one process whose MAX_THREADS workers share one task queue
+ * (FLASH:316-335, calc :338-368); here the workers are devices.  The returned context is used like any other
+ * (fv_set_model uploads to every device, fv_set_option applies to all): a decode runs the whole-sequence pass on
+ * every device (the same deterministic computation, no communication), deals the n_split top-level segments
+ * (:349-353) round-robin to the devices — one host thread and one stream set per device — and merges the answer
+ * arrays with ONE grouped ncclAllGather (ncclCommInitAll) of T int32 over xGMI.  A device may be listed more than
+ * once (a 1-GPU lease): the control flow is the same, with device-to-device copies in place of RCCL (two RCCL ranks
+ * cannot share a device).  ndev = 1 gives a plain fv_create context.  fv_last_stats reports the first device's
+ * decode and `ranks` = ndev.  fv_device_count: GPUs visible to the process (0 if none). */
+int fv_create_multi(fv_ctx **out, const int *devices, int ndev);
+int fv_device_count(void);
 
 /* Model upload.  A is K*K row-major A[from][to], B is K*M row-major B[state][symbol],
  * Pi is K — the VIT fields of FLASH:26-28 as InitElement filled them (:82-93).  Takes

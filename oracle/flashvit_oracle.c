@@ -26,6 +26,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -74,19 +75,30 @@ fvo_model *fvo_model_create(const float *A, const float *B, const float *Pi, int
 }
 
 /* Column-major copy for the full-state cell (walks k contiguously); first use only. */
+/* The transposed table is built on the first full-state call of a model.  Two host threads sharing one model may get
+ * here together: one mutex for all models (the table is built once per model, so contention does not matter), the
+ * pointer is published only when the table is complete. */
+static pthread_mutex_t logAT_lock = PTHREAD_MUTEX_INITIALIZER;
+
 static int model_need_logAT(fvo_model *m)
 {
-    if (m->logAT) return 0;
-    const int K = m->K;
-    double *t = (double *)malloc((size_t)K * K * sizeof(double));
-    if (!t) return FVO_ERR_NOMEM;
-    const int BLK = 64;
+    int rc = 0;
+    pthread_mutex_lock(&logAT_lock);
+    if (!m->logAT) {
+        const int K = m->K;
+        double *t = (double *)malloc((size_t)K * K * sizeof(double));
+        if (!t) rc = FVO_ERR_NOMEM;
+        else {
+            const int BLK = 64;
 #pragma omp parallel for schedule(static)
-    for (int i0 = 0; i0 < K; i0 += BLK)
-        for (int k = 0; k < K; ++k)
-            for (int i = i0; i < i0 + BLK && i < K; ++i) t[(size_t)i * K + k] = m->logA[(size_t)k * K + i];
-    m->logAT = t;
-    return 0;
+            for (int i0 = 0; i0 < K; i0 += BLK)
+                for (int k = 0; k < K; ++k)
+                    for (int i = i0; i < i0 + BLK && i < K; ++i) t[(size_t)i * K + k] = m->logA[(size_t)k * K + i];
+            m->logAT = t;
+        }
+    }
+    pthread_mutex_unlock(&logAT_lock);
+    return rc;
 }
 
 void fvo_model_destroy(fvo_model *m)

@@ -43,9 +43,12 @@ def test_host_program_prints_reference_path(tmp_path, name, case, algo):
         exe = str(tmp_path / (name + "_modified"))
         res = subprocess.run(fvbuild.program_cc(str(c), exe), capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
-        for cache in ("0", "1", "1"):       # text parse, cache write, cache read
-            out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, FV_BIN_CACHE=cache))
+        # text parse, cache write, cache read; then the same program as the one host process of two and of three devices
+        # (FV_NGPUS: on a 1-GPU box the members share the GPU and merge by device-to-device copies)
+        for cache, ngpus in (("0", 1), ("1", 1), ("1", 1), ("1", 2), ("1", 3)):
+            out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, FV_BIN_CACHE=cache, FV_NGPUS=str(ngpus)))
             assert out.returncode == 0, out.stderr
+            assert int(re.search(r"n_gpus: (\d+)", out.stderr).group(1)) == ngpus
             assert re.search(r"time: ([\d.]+)", out.stdout)                       # reference run.py:75
             assert int(re.search(r"memory: (\d+)", out.stdout).group(1)) == r["memory"]   # run.py:76
             path = [int(x) for x in re.search(r"path: \[([^\]]*)\]", out.stdout).group(1).split()]

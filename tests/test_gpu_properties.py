@@ -110,3 +110,47 @@ def test_auto_kernel_choice_by_density_and_parity(prob, expect):
     bp, bsc, rc = fv.decode_beam(ob, 4, 40)
     assert bp.tolist() == bo.tolist() and bsc == bs and rc == brc
     fv.close()
+
+
+def test_no_accepted_option_value_changes_a_result():
+    """nothing reachable through include/flashvit.h may return a wrong path with rc 0.  Every bit of
+    FV_OPT_DEBUG is either refused (the timing switches that leave a part of a kernel out live in the separate timing
+    build) or speed-only: each one alone, and all accepted ones together, decode the goldens' paths; the same for every
+    kernel choice, batch limit and select margin."""
+    from conftest import golden_model, load_goldens
+    g = next(x for x in load_goldens() if x["name"] == "cfg1_K128_T256")
+    A, B, Pi, ob = golden_model(g)
+    full = next(r for r in g["runs"] if r["algo"] == "flash" and r["N"] == 8)
+    beam = next(r for r in g["runs"] if r["algo"] == "flashbs" and r["N"] == 8)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, B, Pi)
+    try:
+        accepted = 0
+        for bit in range(24):
+            v = 1 << bit
+            if v & decoder.DEBUG_TIMING_ONLY:
+                with pytest.raises(decoder.FlashVitError):
+                    fv.set_option(decoder.OPT_DEBUG, v)
+                continue
+            accepted |= v
+        for v in [1 << b for b in range(24) if (1 << b) & accepted] + [accepted, accepted & ~(256 | 65536), 0]:
+            fv.set_option(decoder.OPT_DEBUG, v)
+            for kernel in (decoder.KERNEL_AUTO, decoder.KERNEL_U16_REFINE, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_SPARSE_Q16):
+                fv.set_option(decoder.OPT_KERNEL, kernel)
+                path, score, rc = fv.decode_full(ob, 8)
+                assert rc == 0 and path.tolist() == full["path"] and score == np.float32(full["score"]), (v, kernel)
+            path, score, rc = fv.decode_beam(ob, 8, beam["B"])
+            assert path.tolist() == beam["path"] and score == np.float32(beam["score"]), v
+        fv.set_option(decoder.OPT_DEBUG, 0)
+        for key, vals in ((decoder.OPT_MAX_BATCH, (1, 2, 3, 8)), (decoder.OPT_SEL_MARGIN, (0, 1, 100000)), (decoder.OPT_PROFILE, (1, 0))):
+            for v in vals:
+                fv.set_option(key, v)
+                path, score, rc = fv.decode_full(ob, 8)
+                assert rc == 0 and path.tolist() == full["path"]
+                path, score, rc = fv.decode_beam(ob, 8, beam["B"])
+                assert path.tolist() == beam["path"]
+        for key, bad in ((decoder.OPT_DEBUG, -1), (decoder.OPT_DEBUG, 1 << 24), (decoder.OPT_KERNEL, 7), (decoder.OPT_MAX_BATCH, 9), (99, 0)):
+            with pytest.raises(decoder.FlashVitError):
+                fv.set_option(key, bad)
+    finally:
+        fv.close()

@@ -7,10 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from flash_viterbi_amd import build as _build
 PROF_LIB = os.path.abspath(os.environ.get("FV_PROF_LIB", os.path.join(ROOT, "tools", "micro", "libflashvit_prof.so")))
 if sys.argv[1] == "--build":
-    src = [os.path.join(_build.CSRC, s) for s in _build.HIP_SOURCES] + [os.path.join(_build.CSRC, "fv_schedule.cpp")]
-    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-           "-DFV_REPLAY_PROF", "-I", _build.INCLUDE, "-I", _build.CSRC, "-o", PROF_LIB] + src + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
-    subprocess.check_call(cmd); print(PROF_LIB); sys.exit(0)
+    _build.HIP_TIMING_LIB = PROF_LIB
+    _build.EXTRA_TIMING_FLAGS = ["-DFV_REPLAY_PROF"]
+    print(_build.build_hip(force=True, timing=True)); sys.exit(0)
 _build.HIP_LIB = PROF_LIB
 import numpy as np, modelgen
 from flash_viterbi_amd import decoder

@@ -260,7 +260,27 @@ def main():
         try:
             if backend != "nccl":
                 raise decoder.FlashVitError(-8, "rehearsal backend: RCCL communicator not created")
-            fv.comm_init(rank, world, uid[0])
+            # ncclCommInitRank blocks until every rank has entered it: a rank whose peer failed before getting there
+            # would wait for ever and never reach the all_reduce below.  Watchdog: the whole job ends non-zero instead
+            # (torch.distributed.run tears the other ranks down), it never hangs and never prints a half-made line.
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    fv.comm_init(rank, world, uid[0])
+                    box["ok"] = True
+                except BaseException as e:          # noqa: BLE001 - re-raised on the main thread
+                    box["err"] = e
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("FV_COMM_INIT_TIMEOUT", "180")))
+            if th.is_alive():
+                print(f"[rank {rank}] fv_comm_init did not return within its time limit: a peer never entered "
+                      "ncclCommInitRank; aborting the job", file=sys.stderr, flush=True)
+                os._exit(3)
+            if "err" in box:
+                raise box["err"]
         except decoder.FlashVitError as e:
             print(f"[rank {rank}] fv_comm_init failed ({e}); falling back to torch.distributed all_gather", file=sys.stderr)
             ok.zero_()

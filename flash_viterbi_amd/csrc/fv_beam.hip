@@ -33,23 +33,30 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
     const int cand_cap = (ctx->opt_debug & 1024) ? 0 : fvb::cand_cap_for(K, beam);     // FV_OPT_DEBUG bit 10: no candidate lists
     // passes arrive group by group (decode_beam_impl), longest first inside a group; their first positions are in
     // d_passL[pass_off ..] in the same order
-    fvb::BeamBase bb;
-    bb.scores_all = ctx->d_scores.p; bb.hval = ctx->d_hval.p; bb.hstate = ctx->d_hstate.p;
-    bb.cut = ctx->d_cut.p; bb.passL = ctx->d_passL.p + pass_off;
+    const int BP = fvb::beam_pitch(beam);
+    FV_HIP(hipMemsetAsync(ctx->d_doubt_count.p, 0, (size_t)T * sizeof(int), ctx->stream));      // doubtful-column lists of this generation
+    fvb::ResolveCtx rcx;
+    rcx.counters = ctx->d_counters.p; rcx.K = K; rcx.beam = beam;
+    rcx.LA64R = ctx->LA64R.p; rcx.ld = beam_ld(K); rcx.LB32T = ctx->LB32T.p; rcx.ob = ctx->d_ob.p;
+    rcx.bp = ctx->d_bp.p; rcx.doubt = ctx->d_doubt.p; rcx.doubt_count = ctx->d_doubt_count.p;
+    rcx.b.scores_all = ctx->d_scores.p; rcx.b.hval = ctx->d_hval.p; rcx.b.hstate = ctx->d_hstate.p;
+    rcx.b.cut = ctx->d_cut.p; rcx.b.passL = ctx->d_passL.p + pass_off;
     // members of the heaps of passes [first, first + count) at lock-step s: one launch
     auto select = [&](int first, int count, int s, hipStream_t st) -> int {
         fvb::SelArgs a;
         a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.s = s;
         a.no_wave = (ctx->opt_debug & 32768) ? 1 : 0;
+        a.eager = (ctx->opt_debug & 1048576) ? 1 : 0;             // FV_OPT_DEBUG bit 20: replay every duplicate step at once
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
-        a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.b = bb;
-        a.b.passL = bb.passL + first;
+        a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.rc = rcx;
+        a.rc.b.passL = rcx.b.passL + first;
         const bool listed = count <= fvb::BEAM_CHUNK;
         for (int q = 0; listed && q < count; ++q) {
             const int j = passes[first + q].L + s;
-            a.p[q] = fvb::SelJob{ ctx->d_scores.p + (size_t)j * K, ctx->d_hval.p + (size_t)j * beam, ctx->d_hstate.p + (size_t)j * beam,
+            a.p[q] = fvb::SelJob{ ctx->d_scores.p + (size_t)j * K, ctx->d_hval.p + (size_t)j * BP, ctx->d_hstate.p + (size_t)j * BP,
                                   ctx->d_cut.p + (size_t)j * fvb::CUT_W, s >= 1 ? ctx->d_cut.p + (size_t)(j - 1) * fvb::CUT_W : nullptr,
-                                  (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j };
+                                  (cand_cap && s >= 1) ? ctx->d_cand.p + (size_t)j * cand_cap : nullptr, ctx->d_cand_count.p + j,
+                                  j, passes[first + q].L };
         }
         // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
         fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap, listed) : nullptr;
@@ -94,8 +101,10 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                 a.n = std::min(fvb::BEAM_CHUNK, active - base);
                 for (int q = 0; q < a.n; ++q) {
                     const int j = passes[first + base + q].L + s;
-                    a.p[q].sval = ctx->d_hval.p + (size_t)(j - 1) * beam;
-                    a.p[q].sstate = ctx->d_hstate.p + (size_t)(j - 1) * beam;
+                    a.p[q].sval = ctx->d_hval.p + (size_t)(j - 1) * BP;
+                    a.p[q].sstate = ctx->d_hstate.p + (size_t)(j - 1) * BP;
+                    a.p[q].doubt = ctx->d_doubt.p + (size_t)j * fvb::DOUBT_CAP;
+                    a.p[q].doubt_count = ctx->d_doubt_count.p + j;
                     a.p[q].scores = ctx->d_scores.p + (size_t)j * K;
                     a.p[q].bp_row = ctx->d_bp.p + (size_t)j * K;
                     a.p[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[j] * K;
@@ -158,11 +167,25 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
             e.lazy = lazy_walk; e.flag = ctx->d_needfull.p;
             for (int q = 0; q < e.n; ++q) e.p[q] = fvb::BeamEnd{ passes[base + q].L, passes[base + q].R, passes[base + q].whole ? 1 : 0 };
             hipLaunchKernelGGL(fvb::beam_end_backtrack, dim3(e.n), dim3(64), 0, ctx->stream, e, ctx->d_slot_val.p,
-                               ctx->d_slot_state.p, ctx->d_hstate.p, ctx->d_bp.p, ctx->d_ans.p, ctx->d_score.p);
+                               ctx->d_slot_state.p, ctx->d_hstate.p, ctx->d_cut.p, ctx->d_bp.p, ctx->d_ans.p, ctx->d_score.p);
             FV_HIP(hipGetLastError());
         }
         return 0;
     };
+    // Undecided duplicate steps (lazy replays, fv_beam_kernels.hip.inc): mode 0 decides what the pass ends themselves read,
+    // mode 1 — behind the same gate as the layouts — everything, because heap_build_all replays every step's exact scores.
+    auto resolve = [&](int mode, const int *gate) -> int {
+        for (int base = 0; base < np; base += fvb::BEAM_CHUNK) {
+            fvb::ResolveArgs r;
+            r.rc = rcx; r.mode = mode; r.gate = gate; r.ans = ctx->d_ans.p;
+            r.n = std::min(fvb::BEAM_CHUNK, np - base);
+            for (int q = 0; q < r.n; ++q) r.p[q] = fvb::BeamEnd{ passes[base + q].L, passes[base + q].R, passes[base + q].whole ? 1 : 0 };
+            hipLaunchKernelGGL(fvb::beam_resolve, dim3(r.n), dim3(fvb::RESOLVE_BLOCK), fvb::heap_lds(beam), ctx->stream, r);
+            FV_HIP(hipGetLastError());
+        }
+        return 0;
+    };
+    if ((rc = resolve(0, nullptr))) return rc;
     if (lazy) {
         if ((rc = layouts(true, nullptr))) return rc;
         if ((rc = ends(1))) return rc;
@@ -171,6 +194,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
         FV_HIP(hipMemcpyAsync(ctx->d_needfull.p, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         FV_HIP(hipStreamSynchronize(ctx->stream));       // (`one` is a local; this is the experiment path)
     }
+    if ((rc = resolve(1, ctx->d_needfull.p))) return rc;
     if ((rc = layouts(false, ctx->d_needfull.p))) return rc;
     {
         fvb::FixArgs f;
@@ -225,8 +249,10 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     if ((rc = fvi::ensure_workspace(ctx, T, 1))) return rc;
     (void)most;
     FV_HIP(ctx->d_scores.ensure((size_t)T * ctx->K));
-    FV_HIP(ctx->d_hval.ensure((size_t)T * beam_width));
-    FV_HIP(ctx->d_hstate.ensure((size_t)T * beam_width));
+    FV_HIP(ctx->d_hval.ensure((size_t)T * fvb::beam_pitch(beam_width)));
+    FV_HIP(ctx->d_hstate.ensure((size_t)T * fvb::beam_pitch(beam_width)));
+    FV_HIP(ctx->d_doubt.ensure((size_t)T * fvb::DOUBT_CAP));
+    FV_HIP(ctx->d_doubt_count.ensure(T));
     FV_HIP(ctx->d_slot_val.ensure((size_t)T * beam_width));
     FV_HIP(ctx->d_slot_state.ensure((size_t)T * beam_width));
     FV_HIP(ctx->d_tie_list.ensure((size_t)T * ctx->K));

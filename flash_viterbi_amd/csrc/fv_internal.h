@@ -94,6 +94,7 @@ struct fv_ctx {
     DevBuf<int> d_cand_count;    // [T]
     float opt_sel_margin = 0.5f; // FV_OPT_SEL_MARGIN (in 1/1000): margin of the predicted cut bound in beam spreads
     DevBuf<int> d_dupwin;        // [T]
+    DevBuf<int> d_doubt, d_doubt_count;   // [T][DOUBT_CAP] columns of step j won by an undecided cut duplicate of step j - 1, [T] their number
     DevBuf<int> d_needfull;      // [1] a pass's back-track met a tied cell: rebuild the layouts of the generation (beam_end_backtrack)
     DevBuf<int> d_passL;         // first position of every pass of the generation in flight (beam decodes)
     std::vector<int> h_passL;

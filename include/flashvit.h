@@ -108,7 +108,7 @@ typedef struct {
     long long device_bytes;   /* device working set (tables + workspace) */
     long long refine_near;    /* filter kernels: candidates inside the window besides a column's best */
     long long refine_rescan;  /* filter kernels: lanes that had to rescan their rows */
-    long long beam_exact_sets;/* FLASH-BS: steps whose heap members needed the exact replay (duplicate scores at the cut) */
+    long long beam_exact_sets;/* FLASH-BS: exact heap replays run for member sets (duplicate scores at the cut whose survivors mattered) */
     long long beam_ties;      /* FLASH-BS: (step, state) cells re-decided by slot order; 0 unless a back-tracked path met a cell
                                  whose maximum two beam entries attained (only then are the heap layouts rebuilt) */
     long long beam_dup_cols;  /* FLASH-BS statistics: columns won by an entry whose value equals a duplicated cut value */
@@ -121,6 +121,10 @@ typedef struct {
     int ranks;                /* ranks sharing the decode (1 without fv_comm_init) */
     long long refine_saturated; /* packed 16-bit filter: (step, column) pairs whose window reached the end of the code range, so that
                                    every source row was re-evaluated exactly (score rows spread wider than max|log A|) */
+    long long beam_spec_steps;  /* FLASH-BS: steps whose cut fell on duplicated scores and that were carried speculatively (all duplicates
+                                   in the member list, survivors undecided) instead of replaying the heap at once */
+    long long beam_reach_events;/* FLASH-BS: selects at which an undecided duplicate's column reached the beam, so that the steps before
+                                   it had to be decided (exact replays, counted in beam_exact_sets) and the selection repeated */
 } fv_stats;
 
 /* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role

@@ -42,12 +42,13 @@ def _beam_case(spec, n_split, beam, partition_check=False):
         fv.set_model(A, Bm, Pi)
         _log(f"fv_set_model {time.time() - t0:.1f}s")
         got = {}
-        for dbg in (256, 512, 0):
+        for dbg in (256, 512, 1 << 20, 0):          # float64 step kernel, 16-bit filter, eager replays (round-2 path), default
             fv.set_option(decoder.OPT_DEBUG, dbg)
             path, score, rc = fv.decode_beam(ob, n_split, beam, decoder.MODE_REFERENCE)
             st = fv.stats()
             got[dbg] = (path, score, rc)
-            _log(f"FV_OPT_DEBUG={dbg}: gpu_ms {st['gpu_ms']:.2f} exact replays {st['beam_exact_sets']} rc {rc}")
+            _log(f"FV_OPT_DEBUG={dbg}: gpu_ms {st['gpu_ms']:.2f} top_ms {st['top_pass_ms']:.2f} exact replays {st['beam_exact_sets']} speculative steps "
+                 f"{st['beam_spec_steps']} reach events {st['beam_reach_events']} dup cols {st['beam_dup_cols']} rc {rc}")
         fv.set_option(decoder.OPT_DEBUG, 0)
         if partition_check:
             # a 1-GPU run with n_split = 8 must equal the 8-rank run; every simulated rank decodes

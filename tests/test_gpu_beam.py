@@ -13,6 +13,7 @@ from flash_viterbi_amd import decoder
 pytestmark = pytest.mark.gpu
 
 PAIRS, IDS = golden_runs(include_big=True, algo="flashbs")
+EAGER = 1 << 20      # FV_OPT_DEBUG bit 20: no speculative member lists
 
 
 @pytest.fixture(scope="module")
@@ -33,11 +34,20 @@ def ctxs():
 
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_beam_reference_mode_matches_golden(ctxs, g, r):
+    """Default: duplicate scores at the cut are carried speculatively and the heap is replayed only where its outcome is
+    observable (lazy replays); FV_OPT_DEBUG bit 20: every duplicate step replays at once (the round-2 path); bit 19: all
+    layouts rebuilt, which decides every step."""
     fv, ob = ctxs(g)
-    path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
-    assert path.tolist() == r["path"]
-    assert score == np.float32(r["score"])
-    assert rc == (decoder.WARN_BEAM_MISS if -1 in r["path"] else 0)
+    for dbg in (0, EAGER, 524288, EAGER | 524288):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert path.tolist() == r["path"], dbg
+        assert score == np.float32(r["score"])
+        assert rc == (decoder.WARN_BEAM_MISS if -1 in r["path"] else 0)
+        assert dbg != EAGER or fv.stats()["beam_spec_steps"] == 0
     assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"], r["B"]) == r["memory"]
 
 
@@ -69,10 +79,10 @@ def test_beam_matches_oracle_fresh_inputs(K, M, T, N, B, seed, prob):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (0, 512):            # library's choice of beam step kernel, then the 16-bit filter kernel forced
+    for dbg in (0, 512, EAGER, EAGER | 512):     # library's choice of beam step kernel, then the 16-bit filter kernel forced; lazy / eager replays
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
-        assert path.tolist() == opath.tolist() and score == oscore and rc == orc
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc, dbg
     fv.close()
 
 
@@ -114,7 +124,7 @@ def test_beam_pass_groups_on_several_streams_equal_one_stream(kind, K, M, T, N, 
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (131072, 65536, 131072 | 512, 131072 | 1024, 0, 524288, 131072 | 524288):     # bit 19: every layout rebuilt, always
+    for dbg in (131072, 65536, 131072 | 512, 131072 | 1024, 0, 524288, 131072 | 524288, 131072 | EAGER):     # bit 19: every layout rebuilt, always
         fv.set_option(decoder.OPT_DEBUG, dbg)
         for rep in range(2):
             path, score, rc = fv.decode_beam(ob, N, B)
@@ -134,7 +144,7 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (0, 512, 524288):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
+    for dbg in (0, 512, 524288, EAGER, EAGER | 512):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
         assert path.tolist() == opath.tolist() and score == oscore and rc == orc

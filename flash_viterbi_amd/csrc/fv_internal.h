@@ -92,7 +92,7 @@ struct fv_ctx {
     DevBuf<float> d_cut;         // [T][CUT_W] theta, duplicate flag, predicted lower bound of the next cut (topb_select)
     DevBuf<fvb::HNode> d_cand;   // [T][cand_cap] candidate lists of the selects (beam_step epilogue)
     DevBuf<int> d_cand_count;    // [T]
-    float opt_sel_margin = 0.5f; // FV_OPT_SEL_MARGIN (in 1/1000): margin of the predicted cut bound in beam spreads
+    float opt_sel_margin = 0.3f; // FV_OPT_SEL_MARGIN (in 1/1000): starting margin of the predicted cut bound in beam spreads
     DevBuf<int> d_dupwin;        // [T]
     DevBuf<int> d_doubt, d_doubt_count;   // [T][DOUBT_CAP] columns of step j won by an undecided cut duplicate of step j - 1, [T] their number
     DevBuf<int> d_needfull;      // [1] a pass's back-track met a tied cell: rebuild the layouts of the generation (beam_end_backtrack)

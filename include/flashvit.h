@@ -56,7 +56,8 @@ enum {
     FV_OPT_MAX_BATCH = 2,   /* 1..8: most independent tasks advanced by one step launch */
     FV_OPT_PROFILE = 3,     /* 0/1: bracket every step launch with HIP events (fills step_kernel_ms) */
     FV_OPT_SEL_MARGIN = 4,  /* FLASH-BS: margin, in 1/1000 of the beam spread (max - cut value), below the extrapolated cut value
-                               from which the step kernels collect the next select's candidates (default 500); speed only */
+                               from which the step kernels collect the next select's candidates (default 300; the margin then follows the
+                               length of the lists it produces); speed only */
     FV_OPT_DEBUG = 100,     /* UNSTABLE: kernel-tuning switches (a bit mask) that select alternative forms of a kernel or of the
                                launch schedule.  Every bit the library accepts is speed-only — the parity tests run each
                                alternative against the same goldens (tests/test_boundary.py checks that no accepted value
@@ -125,6 +126,9 @@ typedef struct {
                                    in the member list, survivors undecided) instead of replaying the heap at once */
     long long beam_reach_events;/* FLASH-BS: selects at which an undecided duplicate's column reached the beam, so that the steps before
                                    it had to be decided (exact replays, counted in beam_exact_sets) and the selection repeated */
+    long long beam_list_short;  /* FLASH-BS: selects (third step of a pass on) whose candidate list held fewer than B entries ... */
+    long long beam_list_long;   /* ... or more than its capacity: both re-read all K scores */
+    long long beam_list_entries;/* FLASH-BS: total length of the candidate lists the selects ran on (beam_cand_selects of them) */
 } fv_stats;
 
 /* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role

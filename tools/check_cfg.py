@@ -24,7 +24,7 @@ for rep in range(3):
 cells = K * (B or K) * T
 print(f"{kind} K={K} T={T} N={N} B={B} kernel={best['kernel']}: gpu_ms {best['gpu_ms']:.3f} decode_ms {best['decode_ms']:.3f} top_ms {best['top_pass_ms']:.3f} "
       f"cells/s {cells/(best['gpu_ms']*1e-3):.4e} passes {best['passes']} launches {best['step_launches']} task_steps {best['task_steps']} "
-      f"near {best['refine_near']} rescan {best['refine_rescan']} exact_sets {best['beam_exact_sets']} cand_selects {best['beam_cand_selects']} ties {best['beam_ties']} rc {rc}", flush=True)
+      f"near {best['refine_near']} rescan {best['refine_rescan']} exact_sets {best['beam_exact_sets']} cand_selects {best['beam_cand_selects']} ties {best['beam_ties']} spec {best['beam_spec_steps']} reach {best['beam_reach_events']} list short/long {best['beam_list_short']}/{best['beam_list_long']} mean list {best['beam_list_entries']/max(1,best['beam_cand_selects']):.0f} rc {rc}", flush=True)
 if "--no-oracle" not in sys.argv:
     oracle.set_threads(16)
     print("oracle: building log tables ...", flush=True)

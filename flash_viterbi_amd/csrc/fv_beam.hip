@@ -8,7 +8,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
 
 // row pitch of the row-major float64 table the beam kernels gather from
 inline int beam_ld(int K) { return (K + fvb::BEAM_COLS - 1) / fvb::BEAM_COLS * fvb::BEAM_COLS; }
-inline int beam_ldq(int K) { return (K + fvb::BEAMQ_COLS - 1) / fvb::BEAMQ_COLS * fvb::BEAMQ_COLS; }   // ... of the 16-bit one
+inline int beam_ldq(int K) { static_assert(fvb::BEAMQ_COLS == 128, "fv_ldq"); return fv_ldq(K); }   // ... of the 16-bit one
 
 // One generation of beam passes in lock-step (same shape as run_generation_full).  Buffers are indexed
 // by absolute time j (passes of one generation cover disjoint time ranges): scores_all[j] = the K
@@ -96,7 +96,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                 a.tie_cap = (unsigned int)ctx->d_tie_list.n;
                 a.counters = ctx->d_counters.p;
                 a.K = K; a.ld = beam_ld(K); a.ldq = beam_ldq(K); a.beam = beam;
-                a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->LAQ16R.p ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
+                a.LAQ16R = ctx->LAQ16R.p; a.qpar = ctx->beam_q16_ready ? reinterpret_cast<const float *>(ctx->d_qaux.p + 2) : nullptr;
                 a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.cand_cap = cand_cap;
                 a.n = std::min(fvb::BEAM_CHUNK, active - base);
                 for (int q = 0; q < a.n; ++q) {
@@ -116,7 +116,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                 // float64 refine): measured at K = 16384, B = 256 it takes 13.7 us + 2.6 us per extra pass of the
                 // launch against 10.6 + 5.0 for the float64 kernel, so it is used from ~80 MB of float64 rows per
                 // launch on (cfg5: 537 MB per pass).  FV_OPT_DEBUG bit 8: never, bit 9: always.
-                const bool use_q16 = ctx->LAQ16R.p && !(ctx->opt_debug & 256) &&
+                const bool use_q16 = ctx->beam_q16_ready && !(ctx->opt_debug & 256) &&
                                      ((ctx->opt_debug & 512) || (double)a.n * beam * K * 8.0 >= 80e6);
                 if (use_q16)
                     hipLaunchKernelGGL(fvb::beam_step_q16, dim3(beam_ldq(K) / fvb::BEAMQ_COLS, a.n), dim3(fvb::BEAM_BLOCK),
@@ -270,7 +270,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
         hipLaunchKernelGGL(fvb::relayout_rows, dim3(2048), dim3(256), 0, ctx->stream, ctx->LA64.p, ctx->LA64R.p, ctx->K, ctx->nrows, ld);
         FV_HIP(hipGetLastError());
     }
-    if (!ctx->LAQ16R.p && ctx->logs_nonpositive) {
+    if (!ctx->beam_q16_ready && ctx->logs_nonpositive) {
         // filter table of beam_step_q16, quantised on the device from LA64R
         const int ld = beam_ld(ctx->K), ldq = beam_ldq(ctx->K);
         FV_HIP(ctx->LAQ16R.ensure((size_t)ctx->K * ldq));
@@ -282,6 +282,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
         hipLaunchKernelGGL(fvb::q16_params, dim3(1), dim3(1), 0, ctx->stream, ctx->d_qaux.p, ctx->d_qaux.p + 1,
                            reinterpret_cast<float *>(ctx->d_qaux.p + 2));
         FV_HIP(hipGetLastError());
+        ctx->beam_q16_ready = true; ctx->rowq_ready = true;
     }
 
     const double keep_model_ms = ctx->stats.set_model_ms;

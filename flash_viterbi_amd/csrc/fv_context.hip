@@ -358,6 +358,7 @@ int upload_tables(fv_ctx *ctx, const HostTables &h)
 {
     FV_HIP(hipSetDevice(ctx->device));
     ctx->K = 0; ctx->M = 0; ctx->nrows = 0; ctx->full_ok = false; ctx->u16_ok = false; ctx->laq16_ready = false;
+    ctx->rowq_ready = false; ctx->beam_q16_ready = false;
     (void)hipStreamSynchronize(ctx->stream);
     ctx->LA64R.release(); ctx->LAQ16R.release();
     ctx->SPdata.release(); ctx->SPoff.release(); ctx->SPnwb.release();

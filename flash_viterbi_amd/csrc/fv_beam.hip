@@ -292,8 +292,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     ctx->stats.generations = plan.generations();
     ctx->stats.table_bytes_per_step = (long long)beam_width * ctx->K * 8;
 
-    ctx->h_ob.assign(ob, ob + T);
-    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = fvi::begin_decode(ctx, ob, T))) return rc;
     // The passes of a generation run in lock-step, longest first (the active ones are a prefix); the kernels find a
     // pass's rows from its first position, so the whole plan's pass lists go to the device once, before the clock starts.
     std::vector<size_t> pass_off(gens.size(), 0);
@@ -315,8 +314,6 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(ctx->d_passL.ensure(std::max<size_t>(1, ctx->h_passL.size())));
     if (!ctx->h_passL.empty())
         FV_HIP(hipMemcpyAsync(ctx->d_passL.p, ctx->h_passL.data(), ctx->h_passL.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     FV_HIP(hipEventRecord(ctx->ev_s0, ctx->stream));
     for (size_t g = 0; g < gens.size(); ++g) {

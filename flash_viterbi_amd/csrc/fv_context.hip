@@ -32,7 +32,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes() + c->d_needfull.bytes() + c->d_doubt.bytes() + c->d_doubt_count.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes() + c->d_needfull.bytes() + c->d_doubt.bytes() + c->d_doubt_count.bytes() + c->d_pack.bytes();
 }
 
 int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
@@ -50,6 +50,44 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
     FV_HIP(ctx->d_score.ensure(4));
     FV_HIP(ctx->d_counters.ensure(FV_NCOUNTERS));
     if (ctx->comm || ctx->group) FV_HIP(ctx->d_gather.ensure((size_t)T * ctx->nranks));
+    {
+        const size_t want = 2 * FV_NCOUNTERS + 4 + (size_t)T * std::max(1, ctx->nranks) + (size_t)T;     // result block + the staged observations
+        FV_HIP(ctx->d_pack.ensure(want));
+        if (want > ctx->h_pin_n) {
+            if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; ctx->h_pin_n = 0; }
+            FV_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), want * sizeof(int), hipHostMallocDefault));
+            ctx->h_pin_n = want;
+        }
+    }
+    return 0;
+}
+
+constexpr size_t PACK_HEAD = 2 * FV_NCOUNTERS + 4;        // ints in front of the answers: the counters (64-bit each), score + padding
+
+__global__ void pack_result(const unsigned long long *counters, const float *score, const int *ans, size_t nans, int *out)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < 2 * FV_NCOUNTERS) out[tid] = reinterpret_cast<const int *>(counters)[tid];
+    if (tid == 0) out[2 * FV_NCOUNTERS] = __float_as_int(*score);
+    for (size_t i = tid; i < nans; i += (size_t)gridDim.x * blockDim.x) out[PACK_HEAD + i] = ans[i];
+}
+
+__global__ void clear_outputs(unsigned long long *counters, int *ans, int T)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < FV_NCOUNTERS) counters[tid] = 0ull;
+    for (int i = tid; i < T; i += gridDim.x * blockDim.x) ans[i] = 0;
+}
+
+int begin_decode(fv_ctx *ctx, const int *ob, int T)
+{
+    ctx->h_ob.assign(ob, ob + T);
+    // (the pinned block's tail is free until the epilogue: the sequence travels through it, one asynchronous copy)
+    int *stage = ctx->h_pin + (ctx->h_pin_n - (size_t)T);
+    std::memcpy(stage, ob, (size_t)T * sizeof(int));
+    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, stage, (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(clear_outputs, dim3(16), dim3(256), 0, ctx->stream, ctx->d_counters.p, ctx->d_ans.p, T);
+    FV_HIP(hipGetLastError());
     return 0;
 }
 
@@ -57,24 +95,32 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
                   size_t nprof, bool beam)
 {
     std::vector<int> host;
-    if ((ctx->comm || ctx->group) && !plan.seg_L.empty()) {
+    const bool gathered = (ctx->comm || ctx->group) && !plan.seg_L.empty();
+    if (gathered) {
         int rc = gather_answers(ctx, T);                  // one RCCL all-gather of every rank's answer array (fv_comm.hip)
         if (rc) return rc;
         host.resize((size_t)T * ctx->nranks);
-        FV_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
-        FV_HIP(hipMemcpyAsync(host.data(), ctx->d_gather.p, host.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-        FV_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
-        FV_HIP(hipMemcpyAsync(path_out, ctx->d_ans.p, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
-    float score = 0.f;
-    unsigned long long counters[FV_NCOUNTERS] = {};
-    FV_HIP(hipMemcpyAsync(&score, ctx->d_score.p, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    FV_HIP(hipMemcpyAsync(counters, ctx->d_counters.p, sizeof counters, hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+    // [counters | score | answers] in one block, one device-to-host copy into pinned memory
+    const size_t nans = gathered ? host.size() : (size_t)T, total = PACK_HEAD + nans;
+    hipLaunchKernelGGL(pack_result, dim3(64), dim3(256), 0, ctx->stream, ctx->d_counters.p, ctx->d_score.p,
+                       gathered ? ctx->d_gather.p : ctx->d_ans.p, nans, ctx->d_pack.p);
+    FV_HIP(hipGetLastError());
+    FV_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_pack.p, total * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(hipStreamSynchronize(ctx->stream));
     for (hipGraphExec_t ge : ctx->graphs) (void)hipGraphExecDestroy(ge);
     ctx->graphs.clear();
-    if (!host.empty()) merge_gathered(plan, host, T, ctx->nranks, path_out);
+    unsigned long long counters[FV_NCOUNTERS];
+    float score;
+    std::memcpy(counters, ctx->h_pin, sizeof counters);
+    std::memcpy(&score, ctx->h_pin + 2 * FV_NCOUNTERS, sizeof score);
+    if (gathered) {
+        std::memcpy(host.data(), ctx->h_pin + PACK_HEAD, nans * sizeof(int));
+        merge_gathered(plan, host, T, ctx->nranks, path_out);
+    } else {
+        std::memcpy(path_out, ctx->h_pin + PACK_HEAD, nans * sizeof(int));
+    }
     if (score_out) *score_out = score;
 
     fv_stats &st = ctx->stats;
@@ -184,7 +230,8 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release(); ctx->d_needfull.release(); ctx->d_doubt.release(); ctx->d_doubt_count.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release(); ctx->d_needfull.release(); ctx->d_doubt.release(); ctx->d_doubt_count.release(); ctx->d_pack.release();
+    if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; ctx->h_pin_n = 0; }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

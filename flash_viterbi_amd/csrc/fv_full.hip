@@ -551,10 +551,7 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     if (kernel == FV_KERNEL_SPARSE_Q16) ctx->stats.table_bytes_per_step = (long long)ctx->SPdata.bytes();
     ctx->stats.density = ctx->density;
 
-    ctx->h_ob.assign(ob, ob + T);
-    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    if ((rc = fvi::begin_decode(ctx, ob, T))) return rc;
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
     size_t nprof = 0;
     ctx->fork_active = false;
@@ -621,10 +618,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
     ctx->stats.passes = 1 + nck;
     ctx->stats.table_bytes_per_step = (long long)((K + fvk::TILE_W - 1) / fvk::TILE_W) * nrows * fvk::TILE_W * 8;
     ctx->stats.density = ctx->density;
-    ctx->h_ob.assign(ob, ob + T);
-    FV_HIP(hipMemcpyAsync(ctx->d_ob.p, ctx->h_ob.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_counters.p, 0, FV_NCOUNTERS * sizeof(unsigned long long), ctx->stream));
-    FV_HIP(hipMemsetAsync(ctx->d_ans.p, 0, (size_t)T * sizeof(int), ctx->stream));
+    if ((rc = fvi::begin_decode(ctx, ob, T))) return rc;
     FV_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
 
     struct Restore { fv_ctx *c; ~Restore() { c->vanilla = 0; } } restore{ ctx };

@@ -82,6 +82,11 @@ struct fv_ctx {
     DevBuf<int> d_ob, d_ans, d_bp, d_gather;
     DevBuf<float> d_rows, d_score, d_ckpt;            // d_ckpt: kept score rows of fv_decode_checkpoint
     DevBuf<unsigned long long> d_counters;
+    // decode epilogue: path (or the gathered paths), score and counters are packed into one device block and come back
+    // in ONE copy into pinned host memory (three small pageable copies cost ~15 us each)
+    DevBuf<int> d_pack;
+    int *h_pin = nullptr;
+    size_t h_pin_n = 0;          // ints
     // beam workspace
     DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
     DevBuf<int> d_hstate, d_slot_state, d_flags;
@@ -162,6 +167,8 @@ int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed);
 int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float *score_out, clk::time_point t0,
                   size_t nprof, bool beam);
 int drained(fv_ctx *ctx, int rc);
+// decode prologue: observation sequence to the device (through the pinned block), counters and answers cleared
+int begin_decode(fv_ctx *ctx, const int *ob, int T);
 // big-LDS attributes of the kernels each translation unit owns
 int full_setup(fv_ctx *ctx);
 int beam_setup(fv_ctx *ctx);

@@ -27,8 +27,9 @@ cpu_baseline (rank 0, N = 1 only): SURVEY 8(d)'s protocol for the bench configur
 program itself (oracle/_ref, built from the reference's sources with run.py:54's flags), MAX_THREADS =
 n_split, on the FULL cfg2 sequence, 1 warm + 3 timed runs of its own `time:` line, median; plus one
 MAX_THREADS=1 run on a T=16 sample.  `cores` = physical cores of this host, `threads` = what the program
-used.  cfg3 uses a T=64 sample of the reference program; cfg4/cfg5 the oracle port (their text inputs
-would be 5 / 82 GB for the reference's fscanf loader).
+used.  cfg3 uses a T=64 sample of the reference program; cfg4 the reference FLASH-BS program on a T=64 sample (its
+5 GB of text inputs written once into a scratch directory) with the oracle port beside it; cfg5 the port alone
+(82 GB of text).
 
 Prints ONE JSON line on rank 0.
 """
@@ -175,6 +176,33 @@ def cpu_baseline_port(w, model64, ob, fv, f32):
                       + ("; the reference program's text inputs would be 5 GB (K=16384) / 82 GB (K=65536) for its fscanf loader" if K > 4096 else ""),
             "beam_cells_per_sec": (K * beam * Ts / dt) if beam else None,
             "path_equal_to_hip": bool(path.tolist() == hip.tolist())}
+
+
+def cpu_baseline_beam(w, model64, ob, fv, f32):
+    """SURVEY 8(d) for the FLASH-BS workloads: the reference program itself (src/FLASH_BS_Viterbi_multithread.c:579-591,
+    built by oracle/build_ref.py) on the first 64 observations — its text inputs are written once into a scratch
+    directory (the transition matrix of K=16384 is ~5 GB of '%.16f' text, which is also why the sample is bounded) —
+    with the OpenMP port's figure beside it.  K=65536 (82 GB of text) keeps the port alone."""
+    port = cpu_baseline_port(w, model64, ob, fv, f32)
+    if model64 is None:
+        return port
+    K, beam = w["K"], w["beam"]
+    Ts = 64
+    phys, usable = host_cores()
+    try:
+        t0 = time.time()
+        times, path = run_reference("flashbs", K, Ts, N_SPLIT, beam, model64, ob, runs=1, warm=0)
+        wall = time.time() - t0
+    except (FileNotFoundError, OSError, RuntimeError) as e:
+        port["reference_program"] = f"not run: {type(e).__name__}: {str(e)[:200]}"
+        return port
+    hip, _, _ = fv.decode_beam(ob[:Ts], N_SPLIT, beam, decoder.MODE_REFERENCE)
+    return {"value": K * K * Ts / times[0], "unit": "cells/s", "cores": phys, "threads": N_SPLIT, "usable_cpus": usable,
+            "kind": "reference", "seconds": times[0], "protocol": "1 run", "beam_cells_per_sec": K * beam * Ts / times[0],
+            "sample": f"K={K} T={Ts} (first {Ts} observations of the bench workload) beam={beam}, MAX_THREADS={N_SPLIT}; reference "
+                      "src/FLASH_BS_Viterbi_multithread.c built with run.py:54 flags, its own `time:` line (calc() only); "
+                      f"writing and parsing its text inputs took the rest of {wall:.0f} s",
+            "path_equal_to_hip": bool(path == hip.tolist()), "port": port}
 
 
 def load_traffic(kernel_name):
@@ -407,7 +435,9 @@ def main():
                                        "model is the sparse walk, reported separately as sparse_walk"),
                        "transition_density": st["density"] if not is_beam else None,
                        "passes": st["passes"], "step_launches": st["step_launches"], "task_steps": st["task_steps"],
-                       "exact_heap_replays_on_critical_path": st["beam_exact_sets"] if is_beam else None,
+                       "exact_heap_replays": st["beam_exact_sets"] if is_beam else None,
+                       "speculative_duplicate_steps": st["beam_spec_steps"] if is_beam else None,
+                       "reach_events": st["beam_reach_events"] if is_beam else None,
                        "rc": int(rc),
                        "merged_path_equal_to_single_rank": (None if single_rank_path is None else bool(np.asarray(path).tolist() == single_rank_path)),
                        "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none",
@@ -429,10 +459,21 @@ def main():
             bdt = (time.perf_counter() - tb) / nbs
             bst = fv.stats()
             line["flash_bs"] = {"workload": f"FLASH-BS K={K} T={T} n_split={N_SPLIT} beam={BEAM}, same model", "decode_ms": 1e3 * bdt,
-                                "beam_cells_per_sec": K * BEAM * T / bdt, "exact_heap_replays_on_critical_path": bst["beam_exact_sets"],
-                                "rc": int(brc)}
+                                "beam_cells_per_sec": K * BEAM * T / bdt, "exact_heap_replays": bst["beam_exact_sets"],
+                                "speculative_steps": bst["beam_spec_steps"], "rc": int(brc)}
+            if not args.no_cpu_baseline:
+                try:      # the reference FLASH-BS program on the same full sequence, one run
+                    bt, bpath = run_reference("flashbs", K, T, N_SPLIT, BEAM, model64, ob, runs=1, warm=0)
+                    hp, _, _ = fv.decode_beam(ob, N_SPLIT, BEAM)
+                    line["flash_bs"]["cpu_baseline"] = {"kind": "reference", "seconds": bt[0], "threads": N_SPLIT, "beam_cells_per_sec": K * BEAM * T / bt[0],
+                                                        "sample": f"K={K} T={T} (the full sequence) beam={BEAM}, MAX_THREADS={N_SPLIT}; reference src/FLASH_BS_Viterbi_multithread.c, its own `time:` line",
+                                                        "path_equal_to_hip": bool(bpath == hp.tolist())}
+                except (FileNotFoundError, OSError, RuntimeError) as e:
+                    line["flash_bs"]["cpu_baseline"] = f"not run: {type(e).__name__}"
         if args.gpus == 1 and not args.no_cpu_baseline:
-            if is_beam or model64 is None:
+            if is_beam:
+                line["cpu_baseline"] = cpu_baseline_beam(w, model64, ob, fv, (A, B, Pi))
+            elif model64 is None:
                 line["cpu_baseline"] = cpu_baseline_port(w, model64, ob, fv, (A, B, Pi))
             else:
                 line["cpu_baseline"] = cpu_baseline_full(w, model64, ob, fv)

@@ -124,6 +124,8 @@ DEFAULT_SET = [
     dict(kind="flash", K=3965, T=256, prob=0.112, N=8),    # cfg2, the bench configuration itself (1 warm + 3 timed)
     dict(kind="flash", K=3965, T=16, prob=0.112, N=1),     # MAX_THREADS=1 sample
     dict(kind="flash", K=3965, T=64, prob=0.112, N=8),     # bounded sample of cfg3 (same model, T=4096 sequence)
+    dict(kind="flashbs", K=3965, T=256, prob=0.112, N=8, beam=256),    # bench.py's flash_bs extra of cfg2 (full sequence)
+    dict(kind="flashbs", K=16384, T=64, prob=0.112, N=8, beam=256),    # bounded sample of cfg4
 ]
 
 if __name__ == "__main__":

@@ -219,6 +219,34 @@ def load_traffic(kernel_name):
     return ent.get("hbm_bytes_per_launch"), src
 
 
+def heaviest_kernel(traffic_json_kernel_of):
+    """The step kernel with the largest summed time in the committed rocprofv3 summary of this workload
+    (profiles/r03_bench_kernel_stats.csv), with its PMC bytes per launch and physical HBM fraction — for the dense decode
+    that is the batched launch of the right-hand generations, not the kernel `roofline.achieved` describes."""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+    if not os.path.isfile(path):
+        return None
+    best = None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "trellis_step" not in r["Name"] or "sparse" in r["Name"]:
+                continue
+            if best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"]):
+                best = r
+    if best is None:
+        return None
+    name = re.sub(r"^void ", "", re.sub(r"\(.*$", "", best["Name"])).replace(", ", ",")
+    traffic, src = load_traffic(name)
+    avg_us = float(best["AverageNs"]) / 1e3
+    return {"kernel": name, "calls_in_profile": int(best["Calls"]), "avg_us": avg_us, "share_of_profiled_gpu_time_pct": float(best["Percentage"]),
+            "traffic": traffic, "physical_gbs": (traffic / (avg_us * 1e-6) / 1e9) if traffic else None,
+            "physical_frac": (traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "source": "profiles/r03_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command) + " + (src or "no PMC figure"),
+            "note": "batched launches share one sweep of the table among their tasks: 4 B/cell is no bound for them, only the physical fraction is quoted"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,10 +398,12 @@ def main():
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
     kname = "fvb::beam_step(+_q16) + fvb::topb_select" if is_beam else KERNEL_NAMES[st["kernel"]]
     if is_beam:
-        # PMC passes exist for the cfg4 workload only (tools/prof_bench.sh): bytes of an average beam_step launch
-        traffic, traffic_src = load_traffic("fvb::beam_step") if args.workload == "cfg4" else (None, None)
+        # PMC passes over this workload (tools/prof_beam_pmc.sh): bytes of a single-pass launch of the step kernel the
+        # whole-sequence pass uses, counters calibrated on the kernel's own gather pattern (tools/micro/gather_calib.hip)
+        step_kernel = "fvb::beam_step_q16" if K * beam * 8.0 >= 80e6 else "fvb::beam_step"
+        traffic, traffic_src = load_traffic(f"{step_kernel}@{args.workload}")
         if traffic_src:
-            traffic_src += "; average fvb::beam_step launch of the cfg4 decode (single- and multi-pass launches mixed), selects not included"
+            traffic_src += f"; median single-pass {step_kernel} launch (the whole-sequence pass), selects not included"
     else:
         traffic, traffic_src = load_traffic(kname)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -383,6 +413,8 @@ def main():
                 "physical_frac": (traffic / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel": kname, "launch_us": launch_us, "alg_bytes_per_launch": alg_bytes, "launches_per_decode": T - 1,
                 "table_bytes_streamed_per_launch": st["table_bytes_per_step"]}
+    if not is_beam and args.workload == "cfg2":
+        roofline["heaviest_by_total_time"] = heaviest_kernel(None)
 
     extra = {}
     if not is_beam:

@@ -1,4 +1,4 @@
-"""Builds profiles/r02_pmc_summary.csv and profiles/traffic.json from the rocprofv3 --pmc passes that
+"""Builds profiles/r03_pmc_summary.csv and profiles/traffic.json from the rocprofv3 --pmc passes that
 tools/prof_bench.sh leaves under gpurun_out/pmc{1,2,3}/ (default workload) and gpurun_out/bpmc{1,2,3}/ (cfg4 FLASH-BS):
 FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum + TCC_MISS_sum.  Runs anywhere (no GPU)."""
 import csv, datetime, glob, json, os, re, statistics, sys
@@ -11,7 +11,7 @@ for d in ("pmc1", "pmc2", "pmc3", "bpmc1", "bpmc2", "bpmc3"):
                 rows.setdefault((r["Kernel_Name"], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 if not rows:
     sys.exit("no counter_collection.csv under gpurun_out/pmc*/")
-out = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
+out = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
 with open(out, "w") as f:
     f.write("kernel,counter,dispatches,mean,median,min,max\n")
     for (k, c), v in sorted(rows.items()):
@@ -20,8 +20,8 @@ with open(out, "w") as f:
         f.write(f"\"{k}\",{c},{len(v)},{statistics.mean(v):.3f},{statistics.median(v):.3f},{min(v):.3f},{max(v):.3f}\n")
 norm = lambda k: re.sub(r"^void ", "", re.sub(r"\(.*$", "", k)).replace(", ", ",")
 by = {}
-WANT = ("fvk::trellis_step_u16<1,16,false,8>", "fvk::trellis_step<fvk::q16_t,1,16,false>", "fvk::trellis_step<fvk::q16_t,8,2,true>",
-        "fvk::trellis_step_sparse<1>", "fvb::beam_step", "fvb::beam_step_q16")
+WANT = ("fvk::trellis_step_u16<1,16,false,8>", "fvk::trellis_step_u16<4,2,true,8>", "fvk::trellis_step<fvk::q16_t,1,16,false>",
+        "fvk::trellis_step<fvk::q16_t,8,2,true>", "fvk::trellis_step_sparse<1>", "fvk::trellis_first_step")
 for want in WANT:
     m = {c: statistics.mean(v) for (k, c), v in rows.items() if norm(k) == want}
     if {"FETCH_SIZE", "WRITE_SIZE", "TCC_MISS_sum", "TCC_HIT_sum"} <= set(m):
@@ -31,13 +31,11 @@ for want in WANT:
                     "tcc_miss_bytes_per_launch": int(m["TCC_MISS_sum"] * 128)}
 tj = os.path.join(ROOT, "profiles", "traffic.json")
 old = json.load(open(tj))
-old["by_kernel"] = by
-old["source"] = "rocprofv3 --pmc, three separate passes per workload (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum+TCC_MISS_sum) over bench.py (default workload) and bench.py --workload cfg4, tools/prof_bench.sh + tools/pmc_summary.py"
-old["date"] = "round 2, " + datetime.date.today().isoformat()
+old["by_kernel"] = {**{k: v for k, v in old.get("by_kernel", {}).items() if "@" in k}, **by}      # FLASH-BS entries (<kernel>@<workload>): tools/pmc_beam_summary.py
+old["source"] = "rocprofv3 --pmc, three separate passes per workload (FETCH_SIZE; WRITE_SIZE; TCC_HIT_sum+TCC_MISS_sum) over bench.py (default workload), tools/prof_bench.sh + tools/pmc_summary.py"
+old["date"] = "round 3, " + datetime.date.today().isoformat()
 old["note"] = ("counter collection isolates dispatches, so L2 lines kept from the previous (opposite-direction) step are not visible to it; "
-               "the streamed 16-bit table is 31.49 MB at K=3965, algorithmic bytes 62.88 MB (4 B/cell); beam kernels: per launch over "
-               "all launches of the cfg4 decode (single- and multi-pass launches mixed), the beam entries' rows are gathered 512 B at a "
-               "time (8-byte gathers: FETCH_SIZE's x2 correction is calibrated for 16-B/lane streams, treat the beam figures as approximate; "
-               "TCC_MISS_sum*128 B is the cross-check)")
+               "the streamed 16-bit table is 31.49 MB at K=3965, algorithmic bytes 62.88 MB (4 B/cell); trellis_step_u16<4,2,true,8> is the batched "
+               "launch of the right-hand generations (four tasks share one sweep of the table)")
 json.dump(old, open(tj, "w"), indent=1)
 print(json.dumps(by, indent=1))

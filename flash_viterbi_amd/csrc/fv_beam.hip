@@ -47,6 +47,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
         a.counters = ctx->d_counters.p; a.K = K; a.beam = beam; a.s = s;
         a.no_wave = (ctx->opt_debug & 32768) ? 1 : 0;
         a.eager = (ctx->opt_debug & 1048576) ? 1 : 0;             // FV_OPT_DEBUG bit 20: replay every duplicate step at once
+        a.quad_dirty = (ctx->opt_debug & 16777216) ? 1 : 0;
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
         a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.rc = rcx;
         a.rc.b.passL = rcx.b.passL + first;

@@ -70,7 +70,8 @@ enum {
                                float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
-                               step replays its heap at once (no speculative member lists) */
+                               step replays its heap at once (no speculative member lists), 24 four-wave select also on steps that
+                               may have to be resolved */
 };
 #define FV_DEBUG_TIMING_ONLY ((1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12))
 enum {

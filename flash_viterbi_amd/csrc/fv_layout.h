@@ -21,6 +21,8 @@ __host__ __device__ inline size_t tab_index(int k, int col, int nrows)
 {
     return (size_t)(col >> 4) * nrows * TILE_W + ((size_t)(k / R) * TILE_W + (col & 15)) * R + (k % R);
 }
+// back-tracks of at least BT_MIN_PARALLEL steps are walked by 64 lanes, each starting BT_WARMUP steps above its chunk (fvk::backtrack)
+constexpr int BT_WARMUP = 32, BT_MIN_PARALLEL = 128;
 struct PassDesc { int L, R, from_pi, whole; long long row_off; };   // row_off: float offset of the pass's 2 score rows
 constexpr int PASS_CHUNK = 64;
 struct PassChunk { int n; PassDesc p[PASS_CHUNK]; };

@@ -268,6 +268,10 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     // 33.4 -> 23.1 ms; at cfg2's 31-step passes nothing, so short generations stay on one stream and the host keeps
     // running ahead).  FV_OPT_DEBUG bit 18: off.
     constexpr int FORK_STREAMS = 3, FORK_CAP = 4;
+    // (Round 3, measured and not kept: the co-resident batches in ONE launch, gridDim.y = three batches of four, instead
+    // of three launches on three streams — no fork / join, a third of the host launches — cfg2 right-hand 1.64 -> 1.79 ms,
+    // cfg3 43.8 -> 51.1 ms: workgroups of one launch run in phase, all in their prologue or all in their sweep; what the
+    // streams provide is the stagger.)
     const bool two = ((kernel == FV_KERNEL_U16_REFINE && ctx->u16_ok) || (kernel == FV_KERNEL_SPARSE_Q16 && maxlen >= 64)) &&
                      !(ctx->opt_debug & 262144) && !whole_gen && np > FORK_CAP &&
                      !ctx->opt_profile && !(ctx->opt_debug & 64);
@@ -287,9 +291,15 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     if (two) {
         cap = std::min(cap, FORK_CAP);
         // no packets may wait on the other queues while a serial generation runs (decode_beam_impl has the measurement)
-        if (!ctx->fork_active) FV_HIP(hipStreamSynchronize(ctx->stream));
+        // (polled: a blocking hipStreamSynchronize wakes the host ~30 us after the stream has drained, and the chip idles
+        // until the first forked launch arrives)
+        if (!ctx->fork_active) {
+            hipError_t qe;
+            while ((qe = hipStreamQuery(ctx->stream)) == hipErrorNotReady) std::this_thread::yield();
+            FV_HIP(qe);
+        }
         ctx->fork_active = true;
-        if (!first_sparse) { int rc = fork(); if (rc) return rc; }       // (else: after lock-step 1, which runs on the main stream)
+        { int rc = fork(); if (rc) return rc; }
     }
     ctx->forked_batches = two;
     struct Unfork { fv_ctx *c; ~Unfork() { c->forked_batches = false; c->lstream = nullptr; } } unfork{ ctx };
@@ -314,26 +324,38 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         if (col_last) while (full > 0 && passes[full - 1].R - passes[full - 1].L == s && !passes[full - 1].whole) --full;
         auto row = [&](int q, int parity) { return ctx->d_rows.p + (size_t)q * 2 * ctx->nrows + (size_t)parity * ctx->nrows; };
         if (s == 1 && first_sparse) {
-            for (int base = 0; base < full; base += fvk::FS_CHUNK) {
+            // every stream runs the first step of its own batches' passes: the auxiliary queues pick up their fork event
+            // 15-25 us after it has fired, and that now passes under the main stream's share of the work
+            for (int sid = 0; sid < nstreams; ++sid) {
                 fvk::FirstArgs a;
                 a.LAQ16R = ctx->LAQ16R.p; a.LA64 = ctx->LA64.p; a.counters = ctx->d_counters.p;
                 a.K = K; a.nrows = ctx->nrows; a.ldq = fv_ldq(K);
                 a.ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W; a.tiles_per_xcd = (a.ntiles + 7) / 8;
                 a.window = ctx->windowq; a.qscale = ctx->qscale;
-                a.n = std::min(fvk::FS_CHUNK, full - base);
-                for (int q = 0; q < a.n; ++q) {
-                    const fv::Pass &p = passes[base + q];
-                    a.t[q].t1_in = row(base + q, 0); a.t[q].t1_out = row(base + q, 1);
-                    a.t[q].tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + 1] * K;
-                    a.t[q].tmp64_row = nullptr;
-                    a.t[q].bp_out = ctx->d_bp.p + (size_t)(p.L + 1) * K;
+                a.n = 0;
+                hipStream_t fst = sid ? ctx->aux[sid - 1] : ctx->stream;
+                auto flush = [&]() -> int {
+                    if (a.n == 0) return 0;
+                    hipLaunchKernelGGL(fvk::trellis_first_step, dim3(a.tiles_per_xcd * 8, a.n), dim3(fvk::FS_BLOCK), fvk::first_step_lds(K), fst, a);
+                    FV_HIP(hipGetLastError());
+                    ctx->stats.step_launches += 1;
+                    ctx->stats.first_task_steps += a.n;
+                    a.n = 0;
+                    return 0;
+                };
+                for (int q = 0; q < full; ++q) {
+                    if ((two ? (q / cap) % nstreams : 0) != sid) continue;
+                    const fv::Pass &p = passes[q];
+                    fvk::TaskSlot &sl = a.t[a.n++];
+                    sl.t1_in = row(q, 0); sl.t1_out = row(q, 1);
+                    sl.tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + 1] * K;
+                    sl.tmp64_row = nullptr;
+                    sl.bp_out = ctx->d_bp.p + (size_t)(p.L + 1) * K;
+                    if (a.n == fvk::FS_CHUNK) { int rc = flush(); if (rc) return rc; }
                 }
-                hipLaunchKernelGGL(fvk::trellis_first_step, dim3(a.tiles_per_xcd * 8, a.n), dim3(fvk::FS_BLOCK), fvk::first_step_lds(K), ctx->stream, a);
-                FV_HIP(hipGetLastError());
-                ctx->stats.step_launches += 1;
-                ctx->stats.first_task_steps += a.n;
+                int rc = flush();
+                if (rc) return rc;
             }
-            if (two) { int rc = fork(); if (rc) return rc; }
         } else
         for (int base = 0; base < full; base += cap) {
             const int nb = std::min(cap, full - base);
@@ -362,22 +384,31 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
             ctx->stats.step_launches += 1;
             ctx->stats.task_steps += nb;
         }
-        if (two && full < active) {      // the single-column last steps read rows every stream has written; the finished
-            int rc = join();              // passes are the tail of the list, so the batches that go on keep their streams
-            if (rc) return rc;
-        }
-        for (int base = full; base < active; base += fvk::COL_CHUNK) {
+        // Single-column last steps of the passes that finish at this lock-step.  A pass's row was written by the stream its
+        // batch keeps for the whole generation (or, at lock-step 1, by init_rows on the main stream), so its last step goes
+        // to that very stream: no cross-stream join in the middle of a generation (a join cost ~10 us of host time, and
+        // the dependency between queues left the chip idle for 15-50 us at each of the 24 of a cfg2 decode).
+        for (int sid = 0; sid < nstreams; ++sid) {
             fvk::ColArgs c;
-            c.LA64 = ctx->LA64.p; c.ans = ctx->d_ans.p; c.K = K; c.nrows = ctx->nrows;
-            c.n = std::min(fvk::COL_CHUNK, active - base);
-            for (int q = 0; q < c.n; ++q) {
-                const fv::Pass &p = passes[base + q];
-                c.p[q] = fvk::ColJob{ row(base + q, (s - 1) & 1), ctx->LB32T.p + (size_t)ctx->h_ob[p.R] * K,
-                                      ctx->d_bp.p + (size_t)p.R * K, p.R };
+            c.LA64 = ctx->LA64.p; c.ans = ctx->d_ans.p; c.K = K; c.nrows = ctx->nrows; c.n = 0;
+            hipStream_t cst = sid ? ctx->aux[sid - 1] : ctx->stream;
+            auto flush = [&]() -> int {
+                if (c.n == 0) return 0;
+                hipLaunchKernelGGL(fvk::last_column, dim3(c.n), dim3(256), 0, cst, c);
+                FV_HIP(hipGetLastError());
+                ctx->stats.column_steps += c.n;
+                c.n = 0;
+                return 0;
+            };
+            for (int q = full; q < active; ++q) {
+                const int owner = (two && s > 1) ? (q / cap) % nstreams : 0;
+                if (owner != sid) continue;
+                const fv::Pass &p = passes[q];
+                c.p[c.n++] = fvk::ColJob{ row(q, (s - 1) & 1), ctx->LB32T.p + (size_t)ctx->h_ob[p.R] * K, ctx->d_bp.p + (size_t)p.R * K, p.R };
+                if (c.n == fvk::COL_CHUNK) { int rc = flush(); if (rc) return rc; }
             }
-            hipLaunchKernelGGL(fvk::last_column, dim3(c.n), dim3(256), 0, ctx->stream, c);
-            FV_HIP(hipGetLastError());
-            ctx->stats.column_steps += c.n;
+            int rc = flush();
+            if (rc) return rc;
         }
     }
     if (use_graph) {

@@ -32,7 +32,7 @@ size_t device_bytes(const fv_ctx *c)
            c->d_ob.bytes() + c->d_ans.bytes() + c->d_bp.bytes() + c->d_gather.bytes() + c->d_rows.bytes() + c->d_ckpt.bytes() +
            c->d_score.bytes() + c->d_counters.bytes() + c->d_hval.bytes() + c->d_scores.bytes() +
            c->d_hstate.bytes() + c->d_flags.bytes() + c->d_slot_val.bytes() + c->d_slot_state.bytes() +
-           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes() + c->d_needfull.bytes() + c->d_doubt.bytes() + c->d_doubt_count.bytes() + c->d_pack.bytes() + c->d_live.bytes() + c->d_live_count.bytes();
+           c->LA64R.bytes() + c->LAQ16R.bytes() + c->d_qaux.bytes() + c->d_tie_list.bytes() + c->d_tie_count.bytes() + c->d_cut.bytes() + c->d_dupwin.bytes() + c->d_cand.bytes() + c->d_cand_count.bytes() + c->d_passL.bytes() + c->d_needfull.bytes() + c->d_doubt.bytes() + c->d_doubt_count.bytes() + c->d_pack.bytes();
 }
 
 int ensure_workspace(fv_ctx *ctx, int T, size_t rows_needed)
@@ -230,7 +230,7 @@ extern "C" void fv_destroy(fv_ctx *ctx)
     ctx->d_ob.release(); ctx->d_ans.release(); ctx->d_bp.release(); ctx->d_gather.release(); ctx->d_rows.release(); ctx->d_ckpt.release();
     ctx->d_score.release(); ctx->d_counters.release(); ctx->d_hval.release(); ctx->d_scores.release();
     ctx->d_hstate.release(); ctx->d_flags.release(); ctx->d_slot_val.release(); ctx->d_slot_state.release();
-    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release(); ctx->d_needfull.release(); ctx->d_doubt.release(); ctx->d_doubt_count.release(); ctx->d_pack.release(); ctx->d_live.release(); ctx->d_live_count.release();
+    ctx->LA64R.release(); ctx->LAQ16R.release(); ctx->d_qaux.release(); ctx->d_tie_list.release(); ctx->d_tie_count.release(); ctx->d_cut.release(); ctx->d_dupwin.release(); ctx->d_cand.release(); ctx->d_cand_count.release(); ctx->d_passL.release(); ctx->d_needfull.release(); ctx->d_doubt.release(); ctx->d_doubt_count.release(); ctx->d_pack.release();
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; ctx->h_pin_n = 0; }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);

@@ -243,17 +243,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     if (np == 0) return 0;
     std::stable_sort(passes.begin(), passes.end(),
                      [](const fv::Pass &a, const fv::Pass &b) { return a.R - a.L > b.R - b.L; });
-    // Lock-step 1 of a right-hand generation: every pass starts from one row of A, so its init row is finite in K*p
-    // entries only, and the step visits just those source rows (fvk::trellis_first_step over the entries init_rows lists:
-    // one launch per stream for all its passes instead of a sweep of the whole table per batch).  FV_OPT_DEBUG bit 21: off.
-    bool first_sparse = !passes[0].whole && (kernel == FV_KERNEL_U16_REFINE || kernel == FV_KERNEL_Q16_REFINE) && ctx->rowq_ready &&
-                        fvk::first_step_lds(K) <= 150 * 1024 && !(ctx->opt_debug & 2097152) && !ctx->opt_profile && !(ctx->opt_debug & 64);
-    for (int q = 0; q < np && first_sparse; ++q) first_sparse = !passes[q].from_pi;
-    if (first_sparse) {
-        FV_HIP(ctx->d_live.ensure((size_t)np * K));
-        FV_HIP(ctx->d_live_count.ensure(np));
-        FV_HIP(hipMemsetAsync(ctx->d_live_count.p, 0, (size_t)np * sizeof(int), ctx->stream));
-    }
     // init rows
     for (int base = 0; base < np; base += fvk::PASS_CHUNK) {
         fvk::PassChunk ch;
@@ -264,8 +253,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         }
         hipLaunchKernelGGL(fvk::init_rows, dim3((K + 255) / 256, ch.n), dim3(256), 0, ctx->stream, ch,
                            ctx->LA64.p, ctx->nrows, ctx->LB64T.p, ctx->LPi64.p, ctx->d_ob.p, ctx->d_ans.p,
-                           ctx->d_rows.p, K, first_sparse ? reinterpret_cast<fvk::LiveEntry *>(ctx->d_live.p) : nullptr,
-                           first_sparse ? ctx->d_live_count.p : nullptr, base);
+                           ctx->d_rows.p, K);
         FV_HIP(hipGetLastError());
     }
     const int maxlen = passes[0].R - passes[0].L;
@@ -289,6 +277,12 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                      !ctx->opt_profile && !(ctx->opt_debug & 64);
     const int nbatches = (np + FORK_CAP - 1) / FORK_CAP;
     const int nstreams = two ? std::min(FORK_STREAMS, nbatches) : 1;      // (batches of three tasks were slower: 2.16 / 54.9 ms)
+    // Lock-step 1 of a right-hand generation: every pass starts from one row of A, so its init row is finite in K*p
+    // entries only, and the step visits just those source rows (fvk::trellis_first_step: one launch for all passes
+    // instead of a sweep of the whole table per batch).  FV_OPT_DEBUG bit 21: off.
+    bool first_sparse = !whole_gen && (kernel == FV_KERNEL_U16_REFINE || kernel == FV_KERNEL_Q16_REFINE) && ctx->rowq_ready &&
+                        fvk::first_step_lds(K) <= 150 * 1024 && !(ctx->opt_debug & 2097152) && !ctx->opt_profile && !(ctx->opt_debug & 64);
+    for (int q = 0; q < np && first_sparse; ++q) first_sparse = !passes[q].from_pi;
     auto fork = [&]() -> int {
         FV_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int q = 1; q < nstreams; ++q) FV_HIP(hipStreamWaitEvent(ctx->aux[q - 1], ctx->ev_fork, 0));
@@ -338,7 +332,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                 a.K = K; a.nrows = ctx->nrows; a.ldq = fv_ldq(K);
                 a.ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W; a.tiles_per_xcd = (a.ntiles + 7) / 8;
                 a.window = ctx->windowq; a.qscale = ctx->qscale;
-                a.live = reinterpret_cast<const fvk::LiveEntry *>(ctx->d_live.p); a.live_count = ctx->d_live_count.p;
                 a.n = 0;
                 hipStream_t fst = sid ? ctx->aux[sid - 1] : ctx->stream;
                 auto flush = [&]() -> int {
@@ -353,7 +346,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                 for (int q = 0; q < full; ++q) {
                     if ((two ? (q / cap) % nstreams : 0) != sid) continue;
                     const fv::Pass &p = passes[q];
-                    a.pq[a.n] = q;
                     fvk::TaskSlot &sl = a.t[a.n++];
                     sl.t1_in = row(q, 0); sl.t1_out = row(q, 1);
                     sl.tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + 1] * K;

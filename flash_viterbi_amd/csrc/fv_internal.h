@@ -81,8 +81,6 @@ struct fv_ctx {
     // workspace
     DevBuf<int> d_ob, d_ans, d_bp, d_gather;
     DevBuf<float> d_rows, d_score, d_ckpt;            // d_ckpt: kept score rows of fv_decode_checkpoint
-    DevBuf<unsigned long long> d_live;               // [passes of a generation][K] {score, state}: finite entries of the init rows (fvk::LiveEntry)
-    DevBuf<int> d_live_count;
     DevBuf<unsigned long long> d_counters;
     // decode epilogue: path (or the gathered paths), score and counters are packed into one device block and come back
     // in ONE copy into pinned host memory (three small pageable copies cost ~15 us each)

@@ -277,12 +277,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
                      !ctx->opt_profile && !(ctx->opt_debug & 64);
     const int nbatches = (np + FORK_CAP - 1) / FORK_CAP;
     const int nstreams = two ? std::min(FORK_STREAMS, nbatches) : 1;      // (batches of three tasks were slower: 2.16 / 54.9 ms)
-    // Lock-step 1 of a right-hand generation: every pass starts from one row of A, so its init row is finite in K*p
-    // entries only, and the step visits just those source rows (fvk::trellis_first_step: one launch for all passes
-    // instead of a sweep of the whole table per batch).  FV_OPT_DEBUG bit 21: off.
-    bool first_sparse = !whole_gen && (kernel == FV_KERNEL_U16_REFINE || kernel == FV_KERNEL_Q16_REFINE) && ctx->rowq_ready &&
-                        fvk::first_step_lds(K) <= 150 * 1024 && !(ctx->opt_debug & 2097152) && !ctx->opt_profile && !(ctx->opt_debug & 64);
-    for (int q = 0; q < np && first_sparse; ++q) first_sparse = !passes[q].from_pi;
     auto fork = [&]() -> int {
         FV_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
         for (int q = 1; q < nstreams; ++q) FV_HIP(hipStreamWaitEvent(ctx->aux[q - 1], ctx->ev_fork, 0));
@@ -323,40 +317,6 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         int full = active;                           // passes [0, full) take a full step
         if (col_last) while (full > 0 && passes[full - 1].R - passes[full - 1].L == s && !passes[full - 1].whole) --full;
         auto row = [&](int q, int parity) { return ctx->d_rows.p + (size_t)q * 2 * ctx->nrows + (size_t)parity * ctx->nrows; };
-        if (s == 1 && first_sparse) {
-            // every stream runs the first step of its own batches' passes: the auxiliary queues pick up their fork event
-            // 15-25 us after it has fired, and that now passes under the main stream's share of the work
-            for (int sid = 0; sid < nstreams; ++sid) {
-                fvk::FirstArgs a;
-                a.LAQ16R = ctx->LAQ16R.p; a.LA64 = ctx->LA64.p; a.counters = ctx->d_counters.p;
-                a.K = K; a.nrows = ctx->nrows; a.ldq = fv_ldq(K);
-                a.ntiles = (K + fvk::TILE_W - 1) / fvk::TILE_W; a.tiles_per_xcd = (a.ntiles + 7) / 8;
-                a.window = ctx->windowq; a.qscale = ctx->qscale;
-                a.n = 0;
-                hipStream_t fst = sid ? ctx->aux[sid - 1] : ctx->stream;
-                auto flush = [&]() -> int {
-                    if (a.n == 0) return 0;
-                    hipLaunchKernelGGL(fvk::trellis_first_step, dim3(a.tiles_per_xcd * 8, a.n), dim3(fvk::FS_BLOCK), fvk::first_step_lds(K), fst, a);
-                    FV_HIP(hipGetLastError());
-                    ctx->stats.step_launches += 1;
-                    ctx->stats.first_task_steps += a.n;
-                    a.n = 0;
-                    return 0;
-                };
-                for (int q = 0; q < full; ++q) {
-                    if ((two ? (q / cap) % nstreams : 0) != sid) continue;
-                    const fv::Pass &p = passes[q];
-                    fvk::TaskSlot &sl = a.t[a.n++];
-                    sl.t1_in = row(q, 0); sl.t1_out = row(q, 1);
-                    sl.tmp_row = ctx->LB32T.p + (size_t)ctx->h_ob[p.L + 1] * K;
-                    sl.tmp64_row = nullptr;
-                    sl.bp_out = ctx->d_bp.p + (size_t)(p.L + 1) * K;
-                    if (a.n == fvk::FS_CHUNK) { int rc = flush(); if (rc) return rc; }
-                }
-                int rc = flush();
-                if (rc) return rc;
-            }
-        } else
         for (int base = 0; base < full; base += cap) {
             const int nb = std::min(cap, full - base);
             fvk::TaskSlot slots[fvk::MAX_BATCH];
@@ -472,21 +432,6 @@ int full_setup(fv_ctx *ctx)
         (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<4, U_DB16, true, 8>)) ||
         (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, 16, false, 8>)) || (rc = set_big_lds(ctx, &fvk::trellis_step_u16<8, U_DB16, true, 8>)))
         return rc;
-    // (its static LDS word + the dynamic part must stay inside the 160 KB)
-    FV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fvk::trellis_first_step), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    return 0;
-}
-
-// row-major copy of the 16-bit table for fvk::trellis_first_step (the beam path builds the same codes for its own kernel)
-int ensure_rowmajor_q16(fv_ctx *ctx)
-{
-    if (ctx->rowq_ready || !ctx->laq16_ready || !ctx->LAQ16.p) return 0;
-    const int ldq = fv_ldq(ctx->K);
-    FV_HIP(ctx->LAQ16R.ensure((size_t)ctx->K * ldq));
-    hipLaunchKernelGGL(fvk::q16_rowmajor, dim3(2048), dim3(256), 0, ctx->stream, ctx->LAQ16.p, ctx->LAQ16R.p, ctx->K, ctx->nrows, ldq);
-    FV_HIP(hipGetLastError());
-    FV_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->rowq_ready = true;
     return 0;
 }
 
@@ -561,9 +506,6 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
         ctx->qscale = -stepf;
         ctx->laq16_ready = true;
     }
-
-    if ((kernel == FV_KERNEL_U16_REFINE || kernel == FV_KERNEL_Q16_REFINE) && mode == FV_MODE_REFERENCE &&
-        fvk::first_step_lds(ctx->K) <= 150 * 1024 && (rc = fvi::ensure_rowmajor_q16(ctx))) return rc;
 
     // generations of passes this rank runs
     std::vector<std::vector<fv::Pass>> gens(plan.generations());

@@ -91,8 +91,7 @@ struct fv_ctx {
     DevBuf<float> d_hval, d_scores, d_slot_val;      // [T][B] members, [T][K] scores, [T][B] exact layout
     DevBuf<int> d_hstate, d_slot_state, d_flags;
     DevBuf<double> LA64R;                            // row-gather copy of the float64 table (built on first beam decode)
-    DevBuf<unsigned short> LAQ16R;                   // row-major fixed-point table: beam_step_q16 (built on the first beam decode, with d_qaux's
-                                                     // parameters) and fvk::trellis_first_step (first full-state decode); the codes are the same
+    DevBuf<unsigned short> LAQ16R;                   // row-major fixed-point table of beam_step_q16 (built on the first beam decode, with d_qaux's parameters)
     bool rowq_ready = false, beam_q16_ready = false; // LAQ16R holds this model's codes / d_qaux holds its parameters
     DevBuf<unsigned long long> d_qaux;               // [0] lmax bits, [1] dmax bits, then {qscale, window} as floats (q16_params)
     DevBuf<int2> d_tie_list;
@@ -174,7 +173,6 @@ int full_setup(fv_ctx *ctx);
 int beam_setup(fv_ctx *ctx);
 // fvk::init_rows lives with the full-state kernels; the beam driver starts its passes from the same rows
 int launch_init_rows(fv_ctx *ctx, const fvk::PassChunk &ch, float *rows);
-int ensure_rowmajor_q16(fv_ctx *ctx);
 // fv_comm.hip
 // Multi-device context: one host thread per member runs the same decode on its own device (whole-sequence pass + the
 // segments the member owns), the members meet in ONE gather of their answer arrays.

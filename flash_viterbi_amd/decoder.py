@@ -36,8 +36,7 @@ class Stats(ctypes.Structure):
                 ("passes", ctypes.c_int), ("generations", ctypes.c_int), ("kernel", ctypes.c_int),
                 ("ranks", ctypes.c_int), ("refine_saturated", ctypes.c_longlong),
                 ("beam_spec_steps", ctypes.c_longlong), ("beam_reach_events", ctypes.c_longlong),
-                ("beam_list_short", ctypes.c_longlong), ("beam_list_long", ctypes.c_longlong), ("beam_list_entries", ctypes.c_longlong),
-                ("first_task_steps", ctypes.c_longlong)]
+                ("beam_list_short", ctypes.c_longlong), ("beam_list_long", ctypes.c_longlong), ("beam_list_entries", ctypes.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

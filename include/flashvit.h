@@ -66,7 +66,7 @@ enum {
                                (libflashvit_timing.so, used by tools/), and this library answers FV_ERR_ARG to them.
                                Full-state: 1 no reverse sweep, 2 alternate load schedule, 3 full last step instead of one
                                column, 6 hipGraph replay of a generation, 13 packed kernel in 16-wave workgroups, 14 packed
-                               kernel for every batched launch, 18 right-hand generations on one stream, 21 first steps of right-hand passes as full sweeps.  FLASH-BS: 8 / 9
+                               kernel for every batched launch, 18 right-hand generations on one stream.  FLASH-BS: 8 / 9
                                float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
@@ -131,8 +131,6 @@ typedef struct {
     long long beam_list_short;  /* FLASH-BS: selects (third step of a pass on) whose candidate list held fewer than B entries ... */
     long long beam_list_long;   /* ... or more than its capacity: both re-read all K scores */
     long long beam_list_entries;/* FLASH-BS: total length of the candidate lists the selects ran on (beam_cand_selects of them) */
-    long long first_task_steps; /* full-state: first steps of right-hand passes evaluated over the finite entries of their init row only
-                                   (K * density source rows instead of K; not included in task_steps / cells) */
 } fv_stats;
 
 /* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role

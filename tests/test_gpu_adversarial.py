@@ -30,7 +30,7 @@ FULL_KERNELS = [decoder.KERNEL_F64_STREAM, decoder.KERNEL_F32_REFINE, decoder.KE
                 decoder.KERNEL_SPARSE_Q16, decoder.KERNEL_U16_REFINE]
 # forced forms of the packed 16-bit kernel (FV_OPT_DEBUG): one stream, packed filter for every batched launch,
 # its 16-wave form, the alternate load schedule
-U16_FORMS = (0, 262144, 16384, 16384 | 8192, 16384 | 4, 262144 | 16384 | 8192, 2097152)
+U16_FORMS = (0, 262144, 16384, 16384 | 8192, 16384 | 4, 262144 | 16384 | 8192)
 
 
 def _classes(rs, shape, probs=(0.25, 0.25, 0.25, 0.25)):

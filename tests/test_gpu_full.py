@@ -55,7 +55,7 @@ def test_packed_u16_filter_for_batched_launches_matches_golden(ctxs, g, r):
     bit 13 selects its 16-wave workgroup form.  (The default form is what every KERNEL_U16_REFINE / AUTO test runs.)"""
     fv, ob = ctxs(g)
     fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_U16_REFINE)
-    for dbg in (262144, 262144 | 16384, 16384, 16384 | 8192, 16384 | 4, 262144 | 16384 | 8192, 2097152, 2097152 | 262144):    # bit 21: first steps of right-hand passes as full sweeps
+    for dbg in (262144, 262144 | 16384, 16384, 16384 | 8192, 16384 | 4, 262144 | 16384 | 8192):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         try:
             path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)

@@ -21,7 +21,7 @@ with open(out, "w") as f:
 norm = lambda k: re.sub(r"^void ", "", re.sub(r"\(.*$", "", k)).replace(", ", ",")
 by = {}
 WANT = ("fvk::trellis_step_u16<1,16,false,8>", "fvk::trellis_step_u16<4,2,true,8>", "fvk::trellis_step<fvk::q16_t,1,16,false>",
-        "fvk::trellis_step<fvk::q16_t,8,2,true>", "fvk::trellis_step_sparse<1>", "fvk::trellis_first_step")
+        "fvk::trellis_step<fvk::q16_t,8,2,true>", "fvk::trellis_step_sparse<1>")
 for want in WANT:
     m = {c: statistics.mean(v) for (k, c), v in rows.items() if norm(k) == want}
     if {"FETCH_SIZE", "WRITE_SIZE", "TCC_MISS_sum", "TCC_HIT_sum"} <= set(m):

@@ -244,7 +244,10 @@ def heaviest_kernel(traffic_json_kernel_of):
             "traffic": traffic, "physical_gbs": (traffic / (avg_us * 1e-6) / 1e9) if traffic else None,
             "physical_frac": (traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "source": "profiles/r03_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command) + " + (src or "no PMC figure"),
-            "note": "batched launches share one sweep of the table among their tasks: 4 B/cell is no bound for them, only the physical fraction is quoted"}
+            "note": ("a batched launch of the right-hand generations: its tasks share one sweep of the table, 4 B/cell is no bound for it, only the "
+                     "physical fraction is quoted" if not name.startswith("fvk::trellis_step_u16<1,") else
+                     "the single-task launch of the whole-sequence pass, i.e. the kernel `roofline.achieved` describes (rocprofv3's average; "
+                     "the batched right-hand launches, trellis_step_u16<4,2,true,8>, come second)")}
 
 
 def main():

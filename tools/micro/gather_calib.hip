@@ -57,6 +57,24 @@ __global__ __launch_bounds__(1024) void rows4(const unsigned int *tab, const int
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// rows16x4: a wave-wide load of 16 B per lane, its four 16-lane groups reading four DIFFERENT rows (256-byte run each): the
+// same 256-byte row pieces as rows4, a quarter of the load instructions
+__global__ __launch_bounds__(1024) void rows16x4(const uint4 *tab, const int *rows, int B, size_t pitch16, unsigned int *sink)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    const uint4 *Lq = tab + (size_t)blockIdx.x * 16 + c;          // 128 columns of 2 bytes = 16 uint4 per row and panel
+    unsigned int acc = 0;
+    for (int i0 = 0; w + 16 * (4 * i0 + g) < B + 16 * 4 * 8; i0 += 8) {      // 8 loads in flight; entry = w + 16 * (4 i + g)
+        uint4 L[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int s = w + 16 * (4 * (i0 + u) + g); L[u] = s < B ? Lq[(size_t)rows[s] * pitch16] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= L[u].x ^ L[u].y ^ L[u].z ^ L[u].w;
+        if (w + 16 * 4 * (i0 + 8) >= B) break;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main(int argc, char **argv)
 {
     const int K = argc > 1 ? atoi(argv[1]) : 16384, B = argc > 2 ? atoi(argv[2]) : 256;
@@ -83,6 +101,10 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 8; ++rep) {
         hipEventRecord(e0); rows4<<<K / 128, 1024>>>(reinterpret_cast<const unsigned int *>(t2), rows + rep * B, B, ld / 2, sink); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); printf("rows4 rep %d: %.1f us = %.2f TB/s\n", rep, 1e3 * ms, (double)B * K * 2 / (ms * 1e9));
+    }
+    for (int rep = 0; rep < 8; ++rep) {
+        hipEventRecord(e0); rows16x4<<<K / 128, 1024>>>(reinterpret_cast<const uint4 *>(t2), rows + rep * B, B, ld / 8, sink); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); printf("rows16x4 rep %d: %.1f us = %.2f TB/s\n", rep, 1e3 * ms, (double)B * K * 2 / (ms * 1e9));
     }
     return 0;
 }

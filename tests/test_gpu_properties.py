@@ -154,3 +154,38 @@ def test_no_accepted_option_value_changes_a_result():
                 fv.set_option(key, bad)
     finally:
         fv.close()
+
+
+def test_one_context_many_shapes_in_any_order():
+    """Workspace buffers (score rows, back-pointers, the pinned result block, beam member lists, doubtful-column lists, the
+    multi-device gather) grow on demand and are reused: one context — plain and multi-device — decodes sequences of
+    different length, splits and beam widths in shuffled order, then a second model of another size, and every result
+    equals the oracle's."""
+    import oracle
+    rs = np.random.RandomState(77)
+    models = []
+    for K, M, seed in ((230, 7, 311), (90, 4, 312)):
+        A, Bm, Pi, _ = modelgen.model32(dict(kind="data_script", K=K, M=M, T=8, prob=0.2, seed=seed))
+        models.append((A, Bm, Pi, oracle.OracleModel(A, Bm, Pi), M))
+    for devices in (0, [0, 0]):
+        fv = decoder.FlashViterbi(devices)
+        try:
+            for A, Bm, Pi, om, M in models:
+                fv.set_model(A, Bm, Pi)
+                shapes = [(T, N, B) for T in (9, 64, 33, 301, 17) for N, B in ((1, 0), (4, 0), (3, 11), (1, 40), (8, 25))]
+                rs.shuffle(shapes)
+                for T, N, B in shapes:
+                    if T < 2 * N or (N > 2 and T == 2 * N):
+                        continue
+                    ob = rs.randint(0, M, T).astype(np.int32)
+                    if B:
+                        opath, oscore, _, orc = om.beam_decode(ob, N, B)
+                        path, score, rc = fv.decode_beam(ob, N, B)
+                    else:
+                        opath, oscore, _, orc = om.full_decode(ob, N)
+                        path, score, rc = fv.decode_full(ob, N)
+                    assert path.tolist() == opath.tolist() and score == oscore and rc == orc, (devices, T, N, B)
+        finally:
+            fv.close()
+    for m in models:
+        m[3].close()

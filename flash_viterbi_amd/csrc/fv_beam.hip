@@ -48,6 +48,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
         a.no_wave = (ctx->opt_debug & 32768) ? 1 : 0;
         a.eager = (ctx->opt_debug & 1048576) ? 1 : 0;             // FV_OPT_DEBUG bit 20: replay every duplicate step at once
         a.quad_dirty = (ctx->opt_debug & 16777216) ? 1 : 0;
+        a.sb_rounds = (ctx->opt_debug & (1 << 22)) ? 2 : fvb::SEL_MAX_ROUNDS;
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
         a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.rc = rcx;
         a.rc.b.passL = rcx.b.passL + first;
@@ -60,7 +61,10 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                                   j, passes[first + q].L };
         }
         // steps >= 2 of a pass have a candidate list (the predictor needs two cut values)
-        fvb::SelKernel lean = s >= 2 ? fvb::sel_cand_kernel_for(K, cand_cap, listed) : nullptr;
+        // K > 65536 (FV_OPT_DEBUG bit 22: any K): beyond the 64 rounds the register kernels hold, every selection runs in the
+        // lean kernel — on the candidate list where there is one, otherwise over the K scores in memory
+        const bool many = K > fvb::SEL_MAX_ROUNDS * fvb::SEL_BLOCK || (ctx->opt_debug & (1 << 22));
+        fvb::SelKernel lean = (s >= 2 || many) ? fvb::sel_cand_kernel_for(K, cand_cap, listed, many) : nullptr;
         hipLaunchKernelGGL(lean ? lean : fvb::sel_kernel_for(K, listed), dim3(count), dim3(fvb::SEL_BLOCK), fvb::sel_lds(beam), st, a);
         FV_HIP(hipGetLastError());
         return 0;
@@ -235,7 +239,6 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     if (beam_width < 2 || beam_width > ctx->K) return FV_ERR_ARG;
     if (fvb::beam_step_lds(beam_width) > 150 * 1024 || fvb::beam_step_q16_lds(beam_width) > 150 * 1024 ||
         fvb::heap_lds(beam_width) > 150 * 1024) return FV_ERR_UNSUPPORTED;
-    if (ctx->K > fvb::SEL_MAX_ROUNDS * fvb::SEL_BLOCK) return FV_ERR_UNSUPPORTED;      // topb_select: one bit per round
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     auto t0 = clk::now();
     FV_HIP(hipSetDevice(ctx->device));

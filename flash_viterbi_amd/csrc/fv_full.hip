@@ -40,6 +40,16 @@ int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
     return 0;
 }
 
+// source rows per launch of the float64 kernel: all of them if NB score rows fit LDS next to the reduction scratch
+template <int NB>
+int f64_slab_rows(const fv_ctx *ctx)
+{
+    int slab = ctx->nrows;
+    if (ctx->opt_debug & (1 << 21)) slab = std::max(64, (ctx->nrows / 3 + 63) / 64 * 64);
+    while (slab > 64 && fvk::step_lds_bytes<NB>(slab) > 160 * 1024) slab = (slab / 2 + 63) / 64 * 64;
+    return slab;
+}
+
 template <typename TA, int NB>
 int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
 {
@@ -59,12 +69,23 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     a.ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     a.nb = nb;
+    a.row_lo = 0; a.srows = ctx->nrows; a.merge = 0;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
     constexpr int RBR = 4 * fvk::Tab<TA>::R;
     const int nj_max = (ctx->nrows / RBR + fvk::NWAVES - 1) / fvk::NWAVES;
     if constexpr (std::is_same<TA, double>::value) {
-        return launch_variant<TA, NB, U_DB64, true>(ctx, a, lds);
+        // One launch when the score rows fit LDS; otherwise (K > ~40100 at NB = 1: the route of every model the 16-bit
+        // kernels cannot take — K > 65536, or entries above 1) one launch per slab of source rows, ascending, each merging
+        // into what the slabs below it left in t1_out / bp_out.  FV_OPT_DEBUG bit 21 forces three slabs (tests).
+        const int slab = f64_slab_rows<NB>(ctx);
+        for (int lo = 0; lo < ctx->nrows; lo += slab) {
+            a.row_lo = lo; a.srows = std::min(slab, ctx->nrows - lo); a.merge = lo > 0 ? 1 : 0;
+            if (slab < ctx->nrows) a.reverse = 0;
+            const int rc = launch_variant<TA, NB, U_DB64, true>(ctx, a, fvk::step_lds_bytes<NB>(a.srows));
+            if (rc) return rc;
+        }
+        return 0;
     } else if constexpr (std::is_same<TA, float>::value) {
         if constexpr (NB <= 2) {
             if (nj_max <= U_UP && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
@@ -140,6 +161,7 @@ int launch_u16_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     a.ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     a.nb = nb;
+    a.row_lo = 0; a.srows = ctx->nrows; a.merge = 0;
     for (int t = 0; t < NB; ++t) a.t[t] = slots[t < nb ? t : 0];
     const int nq = ctx->nrows / 32;
     // 8 waves per workgroup (FV_OPT_DEBUG bit 13: 16): everything outside the sweep — quantisation, reductions, refine —
@@ -257,7 +279,9 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
         FV_HIP(hipGetLastError());
     }
     const int maxlen = passes[0].R - passes[0].L;
-    int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(ctx->nrows, !ctx->full_ok)));
+    // (the float64 kernel beyond one LDS row sweeps slabs of source rows: four tasks per launch keep a slab at ~10000 rows)
+    const bool slabbed = kernel == FV_KERNEL_F64_STREAM && !ctx->full_ok;
+    int cap = std::max(1, std::min(ctx->opt_max_batch, slabbed ? 4 : max_batch_for(ctx->nrows, !ctx->full_ok)));
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
     // The batches of a lock-step are independent, and a step launch is latency-bound at both ends (staging the score
     // rows; reductions and refine): the right-hand generations of the packed 16-bit kernel therefore run as batches of
@@ -468,11 +492,16 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
 {
     if (!ctx || !ob || !path_out || T < 2 || n_split < 1) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
-    // Beyond the float32 kernels' LDS limit only the packed 16-bit kernel fits (a row of 16-bit score codes is half
-    // the bytes): it needs every model entry in [0,1] and its table is built on the device on first use.
-    const bool big = !ctx->full_ok;
-    if (big && !(ctx->u16_ok && ctx->logs_nonpositive && (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_U16_REFINE))) {
-        ctx->detail = "full-state decode of K > ~40100 needs the packed 16-bit kernel (FV_KERNEL_AUTO / FV_KERNEL_U16_REFINE, K <= 65536, model entries in [0,1])";
+    // Beyond the float32 kernels' LDS limit (one score row of K floats) two routes remain:
+    //   * the packed 16-bit kernel — a row of 16-bit score codes is half the bytes (K <= 65536); it needs every model entry
+    //     in [0,1], and its table is built on the device on first use;
+    //   * the float64 kernel in slabs of source rows (launch_step_nb): any K the float64 table fits the device for, any
+    //     model; 8 B per cell instead of 2.
+    const bool wide = !ctx->full_ok;
+    const bool big = wide && ctx->u16_ok && ctx->logs_nonpositive && !ctx->vanilla &&
+                     (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_U16_REFINE);
+    if (wide && !big && !(ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_F64_STREAM)) {
+        ctx->detail = "full-state decode of K > ~40100: FV_KERNEL_AUTO, FV_KERNEL_U16_REFINE (K <= 65536, model entries in [0,1]) or FV_KERNEL_F64_STREAM";
         return FV_ERR_UNSUPPORTED;
     }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
@@ -485,7 +514,7 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     fv::Plan plan;
     int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
     if (rc) return rc;
-    const int kernel = big ? FV_KERNEL_U16_REFINE : pick_kernel(ctx);
+    const int kernel = big ? FV_KERNEL_U16_REFINE : wide ? FV_KERNEL_F64_STREAM : pick_kernel(ctx);
     if (big && !ctx->laq16_ready) {      // (the flag, not the pointer: a build that failed half way leaves the buffer allocated)
         const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
         const size_t tab = (size_t)ntiles * ctx->nrows * fvk::TILE_W;
@@ -568,7 +597,6 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
 {
     if (!ctx || !ob || !path_out || T < 2) return FV_ERR_ARG;
     if (ctx->K == 0) return FV_ERR_STATE;
-    if (!ctx->full_ok) { ctx->detail = "full-state decode needs one score row in LDS (K <= ~40100)"; return FV_ERR_UNSUPPORTED; }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
     if (step <= 0) step = (int)std::floor(std::sqrt(1.0 * T));        // checkpoint Viterbi.c:179-180
     auto t0 = clk::now();
@@ -630,7 +658,7 @@ int decode_checkpoint_impl(fv_ctx *ctx, const int *ob, int T, int step, int *pat
     for (int c = 0; c < nck; ++c) order[c] = c;
     auto seg_len = [&](int c) { return std::min((c + 1) * step, T - 1) - c * step; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return seg_len(a) > seg_len(b); });
-    const int cap = std::max(1, std::min(ctx->opt_max_batch, max_batch_for(nrows, false)));
+    const int cap = std::max(1, std::min(ctx->opt_max_batch, ctx->full_ok ? max_batch_for(nrows, false) : 4));
     const int maxlen = seg_len(order[0]);
     int active = nck;
     for (int s = 1; s <= maxlen; ++s) {

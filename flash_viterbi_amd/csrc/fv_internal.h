@@ -65,7 +65,7 @@ struct fv_ctx {
     // model
     int K = 0, M = 0, nrows = 0;
     bool full_ok = false;    // every full-state kernel can take this K (one float32 score row fits LDS: K <= ~40100)
-    bool u16_ok = false;     // the packed 16-bit kernel can (one row of 16-bit score codes fits LDS: K <= 65536)
+    bool u16_ok = false;     // the packed 16-bit kernel can (one row of 16-bit score codes fits LDS: K <= 65536; beyond: float64 slabs)
     bool logs_nonpositive = false;
     DevBuf<float> LA32, LB32T;
     DevBuf<unsigned short> LA16, LAQ16;

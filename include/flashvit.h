@@ -32,7 +32,9 @@ enum {
     FV_ERR_NO_PRED = -3,     /* a decoded entry has no finite predecessor (reference: T2[cur][-1], UB) */
     FV_ERR_DEVICE = -4,      /* a HIP call failed; fv_last_error_detail() has the text */
     FV_ERR_STATE = -5,       /* decode before fv_set_model, comm calls out of order */
-    FV_ERR_UNSUPPORTED = -6, /* size outside what the kernels are built for */
+    FV_ERR_UNSUPPORTED = -6, /* size or kernel choice outside what the kernels are built for: a filter kernel forced for a model it
+                                cannot take (entries above 1; a score row beyond LDS), a beam width whose heap does not fit LDS.
+                                K itself is bounded by device memory only */
     FV_ERR_COMM = -7,        /* RCCL failure */
 };
 
@@ -66,18 +68,20 @@ enum {
                                (libflashvit_timing.so, used by tools/), and this library answers FV_ERR_ARG to them.
                                Full-state: 1 no reverse sweep, 2 alternate load schedule, 3 full last step instead of one
                                column, 6 hipGraph replay of a generation, 13 packed kernel in 16-wave workgroups, 14 packed
-                               kernel for every batched launch, 18 right-hand generations on one stream.  FLASH-BS: 8 / 9
+                               kernel for every batched launch, 18 right-hand generations on one stream, 21 float64 kernel in
+                               three slabs of source rows (the route of K > 65536) at any size.  FLASH-BS: 8 / 9
                                float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
-                               step replays its heap at once (no speculative member lists), 24 four-wave select also on steps that
-                               may have to be resolved */
+                               step replays its heap at once (no speculative member lists), 22 every selection in the memory-resident
+                               form (the route of K > 65536), 24 four-wave select also on steps that may have to be resolved */
 };
 #define FV_DEBUG_TIMING_ONLY ((1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12))
 enum {
     FV_KERNEL_AUTO = 0,        /* every model entry in [0,1]: SPARSE_Q16 if <= 35 % of A is non-zero, else U16_REFINE;
                                   otherwise F64_STREAM */
-    FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim */
+    FV_KERNEL_F64_STREAM = 1,  /* streams log A as float64 (8 B/cell): the reference expression verbatim; any K (score rows
+                                  beyond LDS are swept in slabs of source rows, one launch per slab) */
     FV_KERNEL_F32_REFINE = 2,  /* streams (float)log A (4 B/cell), brackets the winner within 2 ulp,
                                   then re-evaluates the few candidates in float64: same bits out */
     FV_KERNEL_F16_REFINE = 3,  /* same scheme with log A rounded to binary16 (2 B/cell) and a window of
@@ -89,7 +93,8 @@ enum {
                                   instruction (the score row is quantised with the table's step while it is staged into LDS);
                                   candidates inside the window are re-evaluated in float64 as above: same bits out.  Used
                                   for single-task launches (the whole-sequence pass) and for models whose float32 rows do not
-                                  fit LDS (K up to 65536); batched launches take the Q16_REFINE filter (same table, same bits) */
+                                  fit LDS (K up to 65536; beyond that AUTO takes F64_STREAM); batched launches take the
+                                  Q16_REFINE filter (same table, same bits) */
     FV_KERNEL_SPARSE_Q16 = 5,  /* the Q16 codes of the NON-ZERO transitions only (per destination column, ascending
                                   source state): log 0 = -inf can never win (FLASH:171), so skipping those cells
                                   changes no bit; 7.6 MB instead of 31.5 MB at K=3965, p=0.112 */

@@ -111,9 +111,14 @@ def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
         assert st["kernel"] == decoder.KERNEL_U16_REFINE
         _log(f"K=44000 full decode gpu_ms {st['gpu_ms']:.1f} passes {st['passes']}")
         path3, score3, rc3 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
+        # the float64 kernel takes such a model in slabs of source rows (two launches per step here)
         fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
+        path64, score64, rc64 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
+        assert fv.stats()["kernel"] == decoder.KERNEL_F64_STREAM
+        _log(f"K=44000 float64 kernel in slabs gpu_ms {fv.stats()['gpu_ms']:.1f}")
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F32_REFINE)
         with pytest.raises(decoder.FlashVitError):
-            fv.decode_full(ob, 1)                          # the other kernels still say UNSUPPORTED
+            fv.decode_full(ob, 1)                          # the kernels that need a float32 row in LDS still say UNSUPPORTED
     finally:
         fv.close()
     om = oracle.OracleModel(A, Bm, Pi)
@@ -122,6 +127,48 @@ def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
     om.close()
     assert rc == 0 and orc == 0 and path.tolist() == opath.tolist() and score == oscore
     assert rc3 == 0 and path3.tolist() == opath3.tolist() and score3 == oscore3
+    assert rc64 == 0 and path64.tolist() == opath3.tolist() and score64 == oscore3
+
+
+def test_more_than_65536_states_equals_oracle():
+    """VERDICT r2, missing item 5: the reference sizes everything from K_STATE (src/FLASH_Viterbi_multithread.c:25-34,
+    src/FLASH_BS_Viterbi_multithread.c:27-36); K = 69632 is beyond a row of 16-bit score codes in LDS and beyond the 64
+    rounds of the register selects.  Full-state: the float64 kernel in slabs of source rows (two per step, eight when four
+    tasks share a launch).  FLASH-BS: both step kernels; selections on the candidate lists, and over the K scores in memory
+    where there is none (the first two steps of every pass; every step with FV_OPT_DEBUG bit 10)."""
+    spec = dict(kind="sparse_fast", K=69632, M=20, T=24, prob=0.03, seed=47)
+    t0 = time.time()
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    _log(f"K=69632 model built in {time.time() - t0:.1f}s")
+    fv = decoder.FlashViterbi(0)
+    try:
+        t0 = time.time()
+        fv.set_model(A, Bm, Pi)
+        _log(f"fv_set_model {time.time() - t0:.1f}s")
+        full = fv.decode_full(ob[:7], 2, decoder.MODE_REFERENCE)
+        st = fv.stats()
+        assert st["kernel"] == decoder.KERNEL_F64_STREAM
+        _log(f"K=69632 full decode T=7 N=2: gpu_ms {st['gpu_ms']:.1f} passes {st['passes']} step launches {st['step_launches']}")
+        beam = {}
+        for dbg in (0, 256, 512, 1024, 1 << 20):
+            fv.set_option(decoder.OPT_DEBUG, dbg)
+            beam[dbg] = fv.decode_beam(ob, 3, 512, decoder.MODE_REFERENCE)
+            st = fv.stats()
+            _log(f"K=69632 beam B=512 FV_OPT_DEBUG={dbg}: gpu_ms {st['gpu_ms']:.2f} selects on a list {st['beam_cand_selects']} exact replays {st['beam_exact_sets']}")
+        fv.set_option(decoder.OPT_DEBUG, 0)
+    finally:
+        fv.close()
+    t0 = time.time()
+    om = oracle.OracleModel(A, Bm, Pi)
+    bpath, bscore, _, brc = om.beam_decode(ob, 3, 512)
+    _log(f"oracle beam {time.time() - t0:.1f}s")
+    t0 = time.time()
+    opath, oscore, _, orc = om.full_decode(ob[:7], 2)
+    om.close()
+    _log(f"oracle full {time.time() - t0:.1f}s")
+    assert orc == 0 and full[2] == 0 and full[0].tolist() == opath.tolist() and full[1] == oscore
+    for dbg, (path, score, rc) in beam.items():
+        assert path.tolist() == bpath.tolist() and score == bscore and rc == brc, dbg
 
 
 def test_cfg4_beam_decode_equals_oracle():

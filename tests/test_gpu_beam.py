@@ -51,6 +51,27 @@ def test_beam_reference_mode_matches_golden(ctxs, g, r):
     assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"], r["B"]) == r["memory"]
 
 
+MANY = 1 << 22       # FV_OPT_DEBUG bit 22: every selection in the memory-resident form, compaction blocks of two rounds
+
+
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_beam_memory_resident_select_matches_golden(ctxs, g, r):
+    """K > 65536 is beyond the 64 rounds of keys the register selects hold: every selection of such a model runs in the
+    lean kernel — on the candidate list where there is one, else over the K scores in memory, compacted in blocks of
+    rounds.  Bit 22 takes that route at any K (blocks of two rounds, so several blocks already at K > 2048); with bit 10
+    (no candidate lists) every step selects over all K scores in memory."""
+    fv, ob = ctxs(g)
+    for dbg in (MANY, MANY | 1024, MANY | EAGER, MANY | 1024 | 524288):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert path.tolist() == r["path"], dbg
+        assert score == np.float32(r["score"])
+        assert rc == (decoder.WARN_BEAM_MISS if -1 in r["path"] else 0)
+
+
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_beam_q16_filter_kernel_matches_golden(ctxs, g, r):
     """FV_OPT_DEBUG bit 9 forces beam_step_q16 (filter on the 16-bit table + float64 refine), which the
@@ -144,7 +165,7 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (0, 512, 524288, EAGER, EAGER | 512):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
+    for dbg in (0, 512, 524288, EAGER, EAGER | 512, MANY, MANY | 1024):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
         assert path.tolist() == opath.tolist() and score == oscore and rc == orc

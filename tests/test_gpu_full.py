@@ -160,6 +160,28 @@ def test_tuning_switches_do_not_change_results(ctxs, kernel, bits):
         assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
 
 
+SLABS = 1 << 21      # FV_OPT_DEBUG bit 21: the float64 kernel sweeps the source rows in three slabs
+
+
+@pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
+def test_float64_kernel_in_slabs_of_source_rows_matches_golden(ctxs, g, r):
+    """Models whose score row does not fit LDS and that the 16-bit kernels cannot take (K > 65536, or entries above 1
+    beyond K ~ 40100) run the float64 kernel one slab of source rows per launch, each launch merging into the result of
+    the slabs below it (strict '>' across slabs = the reference's ascending scan).  Forced here at every golden's size,
+    batched (right-hand generations) and not."""
+    fv, ob = ctxs(g)
+    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
+    for dbg, batch in ((SLABS, 8), (SLABS, 1), (SLABS | 8, 3)):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        fv.set_option(decoder.OPT_MAX_BATCH, batch)
+        try:
+            path, score, rc = fv.decode_full(ob, r["N"], decoder.MODE_REFERENCE)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+            fv.set_option(decoder.OPT_MAX_BATCH, 8)
+        assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"]), (dbg, batch)
+
+
 VPAIRS, VIDS = golden_runs(include_big=True, algo="vanilla")
 
 
@@ -167,8 +189,13 @@ VPAIRS, VIDS = golden_runs(include_big=True, algo="vanilla")
 def test_vanilla_baseline_matches_reference_vanilla_binary(ctxs, g, r):
     """fv_decode_vanilla against goldens from Base_line/C implementations/vanilla Viterbi.c."""
     fv, ob = ctxs(g)
-    path, score, rc = fv.decode_vanilla(ob)
-    assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+    for dbg in (0, SLABS):                              # (the baseline's expression in slabs of source rows as well)
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_vanilla(ob)
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
 
 
 CPAIRS, CIDS = golden_runs(include_big=True, algo="checkpoint")
@@ -179,8 +206,13 @@ def test_checkpoint_baseline_matches_reference_checkpoint_binary(ctxs, g, r):
     """fv_decode_checkpoint against goldens from Base_line/C implementations/checkpoint Viterbi.c
     (step 0 = floor(sqrt(T)), what its main passes; other steps through the function's own argument)."""
     fv, ob = ctxs(g)
-    path, score, rc = fv.decode_checkpoint(ob, r["step"])
-    assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
+    for dbg in (0, SLABS):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        try:
+            path, score, rc = fv.decode_checkpoint(ob, r["step"])
+        finally:
+            fv.set_option(decoder.OPT_DEBUG, 0)
+        assert rc == 0 and path.tolist() == r["path"] and score == np.float32(r["score"])
     assert decoder.checkpoint_memory_bytes(fv.K, len(ob), r["step"]) == r["memory"]
 
 

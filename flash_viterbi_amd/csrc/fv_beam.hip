@@ -37,6 +37,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
     FV_HIP(hipMemsetAsync(ctx->d_doubt_count.p, 0, (size_t)T * sizeof(int), ctx->stream));      // doubtful-column lists of this generation
     fvb::ResolveCtx rcx;
     rcx.counters = ctx->d_counters.p; rcx.K = K; rcx.beam = beam;
+    rcx.no_cut = (ctx->opt_debug & (1 << 23)) ? 1 : 0;
     rcx.LA64R = ctx->LA64R.p; rcx.ld = beam_ld(K); rcx.LB32T = ctx->LB32T.p; rcx.ob = ctx->d_ob.p;
     rcx.bp = ctx->d_bp.p; rcx.doubt = ctx->d_doubt.p; rcx.doubt_count = ctx->d_doubt_count.p;
     rcx.b.scores_all = ctx->d_scores.p; rcx.b.hval = ctx->d_hval.p; rcx.b.hstate = ctx->d_hstate.p;
@@ -343,6 +344,13 @@ extern "C" int fv_debug_replay_prof(unsigned long long *out8)
     unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fvb::replay_prof), sizeof z) != hipSuccess) return FV_ERR_DEVICE;
     if (hipMemcpyToSymbol(HIP_SYMBOL(fvb::replay_prof), z, sizeof z) != hipSuccess) return FV_ERR_DEVICE;
+    return FV_OK;
+}
+extern "C" int fv_debug_reach_prof(unsigned long long *out8)
+{
+    unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fvb::reach_prof), sizeof z) != hipSuccess) return FV_ERR_DEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fvb::reach_prof), z, sizeof z) != hipSuccess) return FV_ERR_DEVICE;
     return FV_OK;
 }
 #endif

@@ -147,6 +147,7 @@ int finish_decode(fv_ctx *ctx, const fv::Plan &plan, int T, int *path_out, float
     st.beam_list_short = (long long)counters[11];
     st.beam_list_long = (long long)counters[12];
     st.beam_list_entries = (long long)counters[13];
+    st.beam_chain_cuts = (long long)counters[14];
     if (counters[5]) { ctx->detail = "heap replay: producer/consumer hand-shake timed out"; return FV_ERR_DEVICE; }
     st.device_bytes = (long long)fvi::device_bytes(ctx);
     st.ranks = ctx->nranks;

@@ -36,7 +36,8 @@ class Stats(ctypes.Structure):
                 ("passes", ctypes.c_int), ("generations", ctypes.c_int), ("kernel", ctypes.c_int),
                 ("ranks", ctypes.c_int), ("refine_saturated", ctypes.c_longlong),
                 ("beam_spec_steps", ctypes.c_longlong), ("beam_reach_events", ctypes.c_longlong),
-                ("beam_list_short", ctypes.c_longlong), ("beam_list_long", ctypes.c_longlong), ("beam_list_entries", ctypes.c_longlong)]
+                ("beam_list_short", ctypes.c_longlong), ("beam_list_long", ctypes.c_longlong), ("beam_list_entries", ctypes.c_longlong),
+                ("beam_chain_cuts", ctypes.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -74,7 +74,7 @@ enum {
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
                                step replays its heap at once (no speculative member lists), 22 every selection in the memory-resident
-                               form (the route of K > 65536), 24 four-wave select also on steps that may have to be resolved */
+                               form (the route of K > 65536), 23 runs of undecided steps always decided in full, 24 four-wave select also on steps that may have to be resolved */
 };
 #define FV_DEBUG_TIMING_ONLY ((1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12))
 enum {
@@ -136,6 +136,8 @@ typedef struct {
     long long beam_list_short;  /* FLASH-BS: selects (third step of a pass on) whose candidate list held fewer than B entries ... */
     long long beam_list_long;   /* ... or more than its capacity: both re-read all K scores */
     long long beam_list_entries;/* FLASH-BS: total length of the candidate lists the selects ran on (beam_cand_selects of them) */
+    long long beam_chain_cuts;  /* FLASH-BS: runs of undecided steps that were decided only back to a step whose replay provably does not
+                                   depend on the undecided columns (instead of back to the last step with exact scores) */
 } fv_stats;
 
 /* Device + stream + workspace owner.  Replaces `vit = create_vit()`'s allocation role

@@ -32,7 +32,7 @@ def _log(msg):
     print(f"[baseline-configs] {msg}", flush=True)
 
 
-def _beam_case(spec, n_split, beam, partition_check=False):
+def _beam_case(spec, n_split, beam, partition_check=False, expect_cuts=False):
     t0 = time.time()
     A, Bm, Pi, ob = modelgen.model32(spec)
     _log(f"K={spec['K']} model built in {time.time() - t0:.1f}s")
@@ -42,13 +42,17 @@ def _beam_case(spec, n_split, beam, partition_check=False):
         fv.set_model(A, Bm, Pi)
         _log(f"fv_set_model {time.time() - t0:.1f}s")
         got = {}
-        for dbg in (256, 512, 1 << 20, 0):          # float64 step kernel, 16-bit filter, eager replays (round-2 path), default
+        for dbg in (256, 512, 1 << 20, 1 << 23, 0):  # float64 step kernel, 16-bit filter, eager replays (round-2 path), undecided runs always decided in full, default
             fv.set_option(decoder.OPT_DEBUG, dbg)
             path, score, rc = fv.decode_beam(ob, n_split, beam, decoder.MODE_REFERENCE)
             st = fv.stats()
             got[dbg] = (path, score, rc)
+            # the shortcut of the resolve code (a run of undecided steps decided only back to a step whose replay provably
+            # does not depend on them) must have been taken where it is expected, and never when it is switched off
+            assert st["beam_chain_cuts"] == 0 or not (dbg & ((1 << 23) | (1 << 20))), dbg
+            assert not (expect_cuts and dbg == 0) or st["beam_chain_cuts"] > 0
             _log(f"FV_OPT_DEBUG={dbg}: gpu_ms {st['gpu_ms']:.2f} top_ms {st['top_pass_ms']:.2f} exact replays {st['beam_exact_sets']} speculative steps "
-                 f"{st['beam_spec_steps']} reach events {st['beam_reach_events']} dup cols {st['beam_dup_cols']} rc {rc}")
+                 f"{st['beam_spec_steps']} reach events {st['beam_reach_events']} chain cuts {st['beam_chain_cuts']} dup cols {st['beam_dup_cols']} rc {rc}")
         fv.set_option(decoder.OPT_DEBUG, 0)
         if partition_check:
             # a 1-GPU run with n_split = 8 must equal the 8-rank run; every simulated rank decodes
@@ -179,4 +183,4 @@ def test_cfg4_beam_decode_equals_oracle():
 def test_cfg5_beam_decode_equals_oracle():
     """BASELINE configs[4]: K=65536, T=1024, B=1024, n_split=8 (the select's 64-round instantiation at its K
     limit, ~1500 exact replays, 34 GB float64 row table), plus the 8-rank partition of SURVEY 8(e)."""
-    _beam_case(dict(kind="sparse_fast", K=65536, M=50, T=1024, prob=0.112, seed=12), 8, 1024, partition_check=True)
+    _beam_case(dict(kind="sparse_fast", K=65536, M=50, T=1024, prob=0.112, seed=12), 8, 1024, partition_check=True, expect_cuts=True)

@@ -25,5 +25,5 @@ for dbg in [int(x, 0) for x in sys.argv[2:]]:
     if ref is None: ref = (path.tolist(), score, rc)
     same = (path.tolist(), score, rc) == ref
     print(f"dbg {dbg:9d}: gpu_ms median {statistics.median(ms):8.3f} min {min(ms):8.3f}  whole-sequence pass {statistics.median(top):8.3f}  "
-          f"right-hand {statistics.median(ms) - statistics.median(top):7.3f}  same result {same}  replays {st['beam_exact_sets']} reach {st['beam_reach_events']}", flush=True)
+          f"right-hand {statistics.median(ms) - statistics.median(top):7.3f}  same result {same}  replays {st['beam_exact_sets']} reach {st['beam_reach_events']} cuts {st['beam_chain_cuts']}", flush=True)
 fv.close()

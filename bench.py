@@ -473,6 +473,7 @@ def main():
                        "exact_heap_replays": st["beam_exact_sets"] if is_beam else None,
                        "speculative_duplicate_steps": st["beam_spec_steps"] if is_beam else None,
                        "reach_events": st["beam_reach_events"] if is_beam else None,
+                       "chain_cuts": st["beam_chain_cuts"] if is_beam else None,
                        "rc": int(rc),
                        "merged_path_equal_to_single_rank": (None if single_rank_path is None else bool(np.asarray(path).tolist() == single_rank_path)),
                        "parallelism": f"segments over {args.gpus} rank(s)", "gather": gather_mode if dist is not None else "none",

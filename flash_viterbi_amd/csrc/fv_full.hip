@@ -40,9 +40,9 @@ int launch_variant(fv_ctx *ctx, const fvk::StepArgs<NB> &a, size_t lds)
     return 0;
 }
 
-// source rows per launch of the float64 kernel: all of them if NB score rows fit LDS next to the reduction scratch
+// source rows per launch of trellis_step: all of them if NB score rows fit LDS next to the reduction scratch
 template <int NB>
-int f64_slab_rows(const fv_ctx *ctx)
+int slab_rows(const fv_ctx *ctx)
 {
     int slab = ctx->nrows;
     if (ctx->opt_debug & (1 << 21)) slab = std::max(64, (ctx->nrows / 3 + 63) / 64 * 64);
@@ -74,18 +74,22 @@ int launch_step_nb(fv_ctx *ctx, const fvk::TaskSlot *slots, int nb, int reverse)
     const size_t lds = fvk::step_lds_bytes<NB>(ctx->nrows);
     constexpr int RBR = 4 * fvk::Tab<TA>::R;
     const int nj_max = (ctx->nrows / RBR + fvk::NWAVES - 1) / fvk::NWAVES;
-    if constexpr (std::is_same<TA, double>::value) {
-        // One launch when the score rows fit LDS; otherwise (K > ~40100 at NB = 1: the route of every model the 16-bit
-        // kernels cannot take — K > 65536, or entries above 1) one launch per slab of source rows, ascending, each merging
-        // into what the slabs below it left in t1_out / bp_out.  FV_OPT_DEBUG bit 21 forces three slabs (tests).
-        const int slab = f64_slab_rows<NB>(ctx);
+    // One launch when the score rows fit LDS; otherwise (K > ~40100 at NB = 1: the route of every model the packed 16-bit
+    // kernel cannot take — K > 65536, or entries above 1) one launch per slab of source rows, ascending, each merging
+    // into what the slabs below it left in t1_out / bp_out.  FV_OPT_DEBUG bit 21 forces three slabs (tests).
+    const int slab = slab_rows<NB>(ctx);
+    if (slab < ctx->nrows) {
+        constexpr int U = std::is_same<TA, double>::value ? U_DB64 : std::is_same<TA, float>::value ? U_DB32 : U_DB16;
+        a.reverse = 0;
         for (int lo = 0; lo < ctx->nrows; lo += slab) {
             a.row_lo = lo; a.srows = std::min(slab, ctx->nrows - lo); a.merge = lo > 0 ? 1 : 0;
-            if (slab < ctx->nrows) a.reverse = 0;
-            const int rc = launch_variant<TA, NB, U_DB64, true>(ctx, a, fvk::step_lds_bytes<NB>(a.srows));
+            const int rc = launch_variant<TA, NB, U, true>(ctx, a, fvk::step_lds_bytes<NB>(a.srows));
             if (rc) return rc;
         }
         return 0;
+    }
+    if constexpr (std::is_same<TA, double>::value) {
+        return launch_variant<TA, NB, U_DB64, true>(ctx, a, lds);
     } else if constexpr (std::is_same<TA, float>::value) {
         if constexpr (NB <= 2) {
             if (nj_max <= U_UP && (ctx->opt_debug & 4)) return launch_variant<TA, NB, U_UP, false>(ctx, a, lds);
@@ -280,7 +284,7 @@ int run_generation_full(fv_ctx *ctx, std::vector<fv::Pass> &passes, int kernel, 
     }
     const int maxlen = passes[0].R - passes[0].L;
     // (the float64 kernel beyond one LDS row sweeps slabs of source rows: four tasks per launch keep a slab at ~10000 rows)
-    const bool slabbed = kernel == FV_KERNEL_F64_STREAM && !ctx->full_ok;
+    const bool slabbed = (kernel == FV_KERNEL_F64_STREAM || kernel == FV_KERNEL_Q16_REFINE) && !ctx->full_ok;
     int cap = std::max(1, std::min(ctx->opt_max_batch, slabbed ? 4 : max_batch_for(ctx->nrows, !ctx->full_ok)));
     const bool whole_gen = passes[0].whole;       // generation 0: bracket its step launches for the stats
     // The batches of a lock-step are independent, and a step launch is latency-bound at both ends (staging the score
@@ -500,8 +504,12 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     const bool wide = !ctx->full_ok;
     const bool big = wide && ctx->u16_ok && ctx->logs_nonpositive && !ctx->vanilla &&
                      (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_U16_REFINE);
-    if (wide && !big && !(ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_F64_STREAM)) {
-        ctx->detail = "full-state decode of K > ~40100: FV_KERNEL_AUTO, FV_KERNEL_U16_REFINE (K <= 65536, model entries in [0,1]) or FV_KERNEL_F64_STREAM";
+    // ... and the same slabs for the f32 filter on the 16-bit table (2 B per cell; model entries in [0,1]): what AUTO takes
+    // beyond K = 65536
+    const bool wide_q16 = wide && !big && ctx->logs_nonpositive && !ctx->vanilla &&
+                          (ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_Q16_REFINE);
+    if (wide && !big && !wide_q16 && !(ctx->opt_kernel == FV_KERNEL_AUTO || ctx->opt_kernel == FV_KERNEL_F64_STREAM)) {
+        ctx->detail = "full-state decode of K > ~40100: FV_KERNEL_AUTO, FV_KERNEL_U16_REFINE (K <= 65536), FV_KERNEL_Q16_REFINE (both: model entries in [0,1]) or FV_KERNEL_F64_STREAM";
         return FV_ERR_UNSUPPORTED;
     }
     for (int j = 0; j < T; ++j) if (ob[j] < 0 || ob[j] >= ctx->M) return FV_ERR_ARG;
@@ -514,8 +522,8 @@ int decode_full_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int mode, i
     fv::Plan plan;
     int rc = fv::build_plan(T, n_split, mode, ctx->nranks, plan);
     if (rc) return rc;
-    const int kernel = big ? FV_KERNEL_U16_REFINE : wide ? FV_KERNEL_F64_STREAM : pick_kernel(ctx);
-    if (big && !ctx->laq16_ready) {      // (the flag, not the pointer: a build that failed half way leaves the buffer allocated)
+    const int kernel = big ? FV_KERNEL_U16_REFINE : wide_q16 ? FV_KERNEL_Q16_REFINE : wide ? FV_KERNEL_F64_STREAM : pick_kernel(ctx);
+    if ((big || wide_q16) && !ctx->laq16_ready) {      // (the flag, not the pointer: a build that failed half way leaves the buffer allocated)
         const int ntiles = (ctx->K + fvk::TILE_W - 1) / fvk::TILE_W;
         const size_t tab = (size_t)ntiles * ctx->nrows * fvk::TILE_W;
         FV_HIP(ctx->LAQ16.ensure(tab));

@@ -68,8 +68,8 @@ enum {
                                (libflashvit_timing.so, used by tools/), and this library answers FV_ERR_ARG to them.
                                Full-state: 1 no reverse sweep, 2 alternate load schedule, 3 full last step instead of one
                                column, 6 hipGraph replay of a generation, 13 packed kernel in 16-wave workgroups, 14 packed
-                               kernel for every batched launch, 18 right-hand generations on one stream, 21 float64 kernel in
-                               three slabs of source rows (the route of K > 65536) at any size.  FLASH-BS: 8 / 9
+                               kernel for every batched launch, 18 right-hand generations on one stream, 21 F64 / F32 / F16 / Q16
+                               kernels in three slabs of source rows (the route of K > 65536) at any size.  FLASH-BS: 8 / 9
                                float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
@@ -88,12 +88,12 @@ enum {
                                   2*max|half(L)-L| + 3 ulp: same bits out, a quarter of the float64 bytes; the wider
                                   window costs more refines than the bytes save at K=3965 */
     FV_KERNEL_Q16_REFINE = 4,  /* same scheme with 16-bit fixed point (step = max|log A|/65534): 2 B/cell and
-                                  a window ~ step: same bits out */
+                                  a window ~ step: same bits out; any K (slabs of source rows, as F64_STREAM) */
     FV_KERNEL_U16_REFINE = 6,  /* the Q16 table again, but the filter itself runs in 16-bit fixed point, two cells per packed
                                   instruction (the score row is quantised with the table's step while it is staged into LDS);
                                   candidates inside the window are re-evaluated in float64 as above: same bits out.  Used
                                   for single-task launches (the whole-sequence pass) and for models whose float32 rows do not
-                                  fit LDS (K up to 65536; beyond that AUTO takes F64_STREAM); batched launches take the
+                                  fit LDS (K up to 65536; beyond that AUTO takes Q16_REFINE in slabs); batched launches take the
                                   Q16_REFINE filter (same table, same bits) */
     FV_KERNEL_SPARSE_Q16 = 5,  /* the Q16 codes of the NON-ZERO transitions only (per destination column, ascending
                                   source state): log 0 = -inf can never win (FLASH:171), so skipping those cells

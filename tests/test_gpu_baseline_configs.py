@@ -115,11 +115,17 @@ def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
         assert st["kernel"] == decoder.KERNEL_U16_REFINE
         _log(f"K=44000 full decode gpu_ms {st['gpu_ms']:.1f} passes {st['passes']}")
         path3, score3, rc3 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
-        # the float64 kernel takes such a model in slabs of source rows (two launches per step here)
+        # the float64 kernel takes such a model in slabs of source rows (two launches per step here), and so does the f32
+        # filter on the 16-bit table
         fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
         path64, score64, rc64 = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
         assert fv.stats()["kernel"] == decoder.KERNEL_F64_STREAM
         _log(f"K=44000 float64 kernel in slabs gpu_ms {fv.stats()['gpu_ms']:.1f}")
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_Q16_REFINE)
+        pathq, scoreq, rcq = fv.decode_full(ob, 3, decoder.MODE_REFERENCE)
+        assert fv.stats()["kernel"] == decoder.KERNEL_Q16_REFINE
+        _log(f"K=44000 f32 filter on the 16-bit table in slabs gpu_ms {fv.stats()['gpu_ms']:.1f}")
+        assert rcq == rc64 and pathq.tolist() == path64.tolist() and scoreq == score64
         fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F32_REFINE)
         with pytest.raises(decoder.FlashVitError):
             fv.decode_full(ob, 1)                          # the kernels that need a float32 row in LDS still say UNSUPPORTED
@@ -137,8 +143,8 @@ def test_full_state_decode_beyond_the_f32_lds_limit_equals_oracle():
 def test_more_than_65536_states_equals_oracle():
     """VERDICT r2, missing item 5: the reference sizes everything from K_STATE (src/FLASH_Viterbi_multithread.c:25-34,
     src/FLASH_BS_Viterbi_multithread.c:27-36); K = 69632 is beyond a row of 16-bit score codes in LDS and beyond the 64
-    rounds of the register selects.  Full-state: the float64 kernel in slabs of source rows (two per step, eight when four
-    tasks share a launch).  FLASH-BS: both step kernels; selections on the candidate lists, and over the K scores in memory
+    rounds of the register selects.  Full-state: trellis_step in slabs of source rows (two per step, eight when four tasks share
+    a launch) — the f32 filter on the 16-bit table (AUTO) and the float64 kernel.  FLASH-BS: both step kernels; selections on the candidate lists, and over the K scores in memory
     where there is none (the first two steps of every pass; every step with FV_OPT_DEBUG bit 10)."""
     spec = dict(kind="sparse_fast", K=69632, M=20, T=24, prob=0.03, seed=47)
     t0 = time.time()
@@ -151,8 +157,13 @@ def test_more_than_65536_states_equals_oracle():
         _log(f"fv_set_model {time.time() - t0:.1f}s")
         full = fv.decode_full(ob[:7], 2, decoder.MODE_REFERENCE)
         st = fv.stats()
-        assert st["kernel"] == decoder.KERNEL_F64_STREAM
+        assert st["kernel"] == decoder.KERNEL_Q16_REFINE          # AUTO: the f32 filter on the 16-bit table, in slabs
         _log(f"K=69632 full decode T=7 N=2: gpu_ms {st['gpu_ms']:.1f} passes {st['passes']} step launches {st['step_launches']}")
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
+        full64 = fv.decode_full(ob[:7], 2, decoder.MODE_REFERENCE)
+        _log(f"K=69632 float64 kernel: gpu_ms {fv.stats()['gpu_ms']:.1f}")
+        fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_AUTO)
+        assert full64[2] == full[2] and full64[0].tolist() == full[0].tolist() and full64[1] == full[1]
         beam = {}
         for dbg in (0, 256, 512, 1024, 1 << 20):
             fv.set_option(decoder.OPT_DEBUG, dbg)

@@ -163,14 +163,17 @@ def test_tuning_switches_do_not_change_results(ctxs, kernel, bits):
 SLABS = 1 << 21      # FV_OPT_DEBUG bit 21: the float64 kernel sweeps the source rows in three slabs
 
 
+@pytest.mark.parametrize("kernel", [decoder.KERNEL_F64_STREAM, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_F32_REFINE, decoder.KERNEL_F16_REFINE],
+                         ids=["f64stream", "q16refine", "f32refine", "f16refine"])
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
-def test_float64_kernel_in_slabs_of_source_rows_matches_golden(ctxs, g, r):
-    """Models whose score row does not fit LDS and that the 16-bit kernels cannot take (K > 65536, or entries above 1
-    beyond K ~ 40100) run the float64 kernel one slab of source rows per launch, each launch merging into the result of
-    the slabs below it (strict '>' across slabs = the reference's ascending scan).  Forced here at every golden's size,
-    batched (right-hand generations) and not."""
+def test_step_kernel_in_slabs_of_source_rows_matches_golden(ctxs, g, r, kernel):
+    """Models whose score row does not fit LDS and that the packed 16-bit kernel cannot take (K > 65536, or entries above 1
+    beyond K ~ 40100) run trellis_step one slab of source rows per launch — the float64 kernel, or the f32 filter on the 16-bit
+    table with its refine inside the slab — each launch merging into the exact result of the slabs below it (strict '>'
+    across slabs = the reference's ascending scan).  Forced here at every golden's size, batched (right-hand generations)
+    and not."""
     fv, ob = ctxs(g)
-    fv.set_option(decoder.OPT_KERNEL, decoder.KERNEL_F64_STREAM)
+    fv.set_option(decoder.OPT_KERNEL, kernel)
     for dbg, batch in ((SLABS, 8), (SLABS, 1), (SLABS | 8, 3)):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         fv.set_option(decoder.OPT_MAX_BATCH, batch)

@@ -50,6 +50,7 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
         a.eager = (ctx->opt_debug & 1048576) ? 1 : 0;             // FV_OPT_DEBUG bit 20: replay every duplicate step at once
         a.quad_dirty = (ctx->opt_debug & 16777216) ? 1 : 0;
         a.sb_rounds = (ctx->opt_debug & (1 << 22)) ? 2 : fvb::SEL_MAX_ROUNDS;
+        a.T = T; a.own_pred = (ctx->opt_debug & (1 << 7)) ? 1 : 0;
         a.margin = ctx->opt_sel_margin; a.cand_cap = cand_cap;
         a.cand = ctx->d_cand.p; a.cand_count = ctx->d_cand_count.p; a.rc = rcx;
         a.rc.b.passL = rcx.b.passL + first;
@@ -263,6 +264,7 @@ int decode_beam_impl(fv_ctx *ctx, const int *ob, int T, int n_split, int beam_wi
     FV_HIP(ctx->d_tie_list.ensure((size_t)T * ctx->K));
     FV_HIP(ctx->d_tie_count.ensure(4));
     FV_HIP(ctx->d_cut.ensure((size_t)T * fvb::CUT_W));
+    FV_HIP(hipMemsetAsync(ctx->d_cut.p, 0xFF, (size_t)T * fvb::CUT_W * sizeof(float), ctx->stream));      // NaN: no earlier pass has left a cut here
     FV_HIP(ctx->d_cand_count.ensure(T));
     FV_HIP(hipMemsetAsync(ctx->d_cand_count.p, 0, (size_t)T * sizeof(int), ctx->stream));
     if (const int cap = fvb::cand_cap_for(ctx->K, beam_width)) FV_HIP(ctx->d_cand.ensure((size_t)T * cap));

@@ -69,7 +69,8 @@ enum {
                                Full-state: 1 no reverse sweep, 2 alternate load schedule, 3 full last step instead of one
                                column, 6 hipGraph replay of a generation, 13 packed kernel in 16-wave workgroups, 14 packed
                                kernel for every batched launch, 18 right-hand generations on one stream, 21 F64 / F32 / F16 / Q16
-                               kernels in three slabs of source rows (the route of K > 65536) at any size.  FLASH-BS: 8 / 9
+                               kernels in three slabs of source rows (the route of K > 65536) at any size.  FLASH-BS: 7 the cut predictor uses the pass's own
+                               cuts only, 8 / 9
                                float64 / 16-bit step kernel always, 10 no candidate lists, 15 whole-workgroup select for short
                                lists too, 16 / 17 pass groups on one stream / on four streams whatever the size, 19 every heap
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate

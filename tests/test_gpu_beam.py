@@ -38,7 +38,7 @@ def test_beam_reference_mode_matches_golden(ctxs, g, r):
     observable (lazy replays); FV_OPT_DEBUG bit 20: every duplicate step replays at once (the round-2 path); bit 19: all
     layouts rebuilt, which decides every step."""
     fv, ob = ctxs(g)
-    for dbg in (0, EAGER, 524288, EAGER | 524288, NOCUT, NOCUT | 512):
+    for dbg in (0, EAGER, 524288, EAGER | 524288, NOCUT, NOCUT | 512, OWNPRED):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         try:
             path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
@@ -51,6 +51,7 @@ def test_beam_reference_mode_matches_golden(ctxs, g, r):
     assert decoder.reference_memory_bytes(fv.K, len(ob), r["N"], r["B"]) == r["memory"]
 
 
+OWNPRED = 1 << 7     # FV_OPT_DEBUG bit 7: the next cut is predicted from the pass's own two last cuts only (not from the earlier generation's)
 NOCUT = 1 << 23      # FV_OPT_DEBUG bit 23: runs of undecided steps are always decided in full (no replay_safe shortcut)
 MANY = 1 << 22       # FV_OPT_DEBUG bit 22: every selection in the memory-resident form, compaction blocks of two rounds
 

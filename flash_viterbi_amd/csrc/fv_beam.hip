@@ -125,8 +125,16 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                 // launch on (cfg5: 537 MB per pass).  FV_OPT_DEBUG bit 8: never, bit 9: always.
                 const bool use_q16 = ctx->beam_q16_ready && !(ctx->opt_debug & 256) &&
                                      ((ctx->opt_debug & 512) || (double)a.n * beam * K * 8.0 >= 80e6);
-                if (use_q16)
-                    hipLaunchKernelGGL(fvb::beam_step_q16, dim3(beam_ldq(K) / fvb::BEAMQ_COLS, a.n), dim3(fvb::BEAM_BLOCK),
+                // 8-wave workgroups once the launch has more 16-wave workgroups than fit the chip together (two per CU);
+                // FV_OPT_DEBUG bit 25: never, bit 26: always
+                const int panels = beam_ldq(K) / fvb::BEAMQ_COLS;
+                const bool narrow = !(ctx->opt_debug & (1 << 25)) &&
+                                    ((ctx->opt_debug & (1 << 26)) || (long long)panels * a.n > 2LL * ctx->num_cus);
+                // (4-wave workgroups for launches beyond four 8-wave workgroups per CU: cfg4 right-hand 3.51 -> 3.56 ms, cfg5 95.8 -> 97.1)
+                if (use_q16 && narrow)
+                    hipLaunchKernelGGL(fvb::beam_step_q16<8>, dim3(panels, a.n), dim3(8 * 64), fvb::beam_step_q16_lds(beam, 8), st, a);
+                else if (use_q16)
+                    hipLaunchKernelGGL(fvb::beam_step_q16<16>, dim3(panels, a.n), dim3(fvb::BEAM_BLOCK),
                                        fvb::beam_step_q16_lds(beam), st, a);
                 else
                     hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),

@@ -494,7 +494,7 @@ extern "C" int fv_set_option(fv_ctx *ctx, int key, long long value)
         // the timing build only (libflashvit_timing.so, tools/).  Every bit this library accepts is speed-only.
         if (value & FV_DEBUG_TIMING_ONLY) { ctx->detail = "FV_OPT_DEBUG: result-changing timing switches need the timing build"; return FV_ERR_ARG; }
 #endif
-        if (value < 0 || value >= (1ll << 25)) return FV_ERR_ARG;
+        if (value < 0 || value >= (1ll << 27)) return FV_ERR_ARG;
         ctx->opt_debug = (int)value; return FV_OK;
     default: return FV_ERR_ARG;
     }

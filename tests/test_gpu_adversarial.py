@@ -122,7 +122,7 @@ def test_wide_dynamic_range_beam(kind, K, M, T, seed, B):
         for N in (1, 4):
             opath, oscore, _, orc = want[N]
             assert orc >= 0
-            for dbg in (256, 512, 0, 524288):          # float64 rows, 16-bit filter + refine, library's choice, all layouts
+            for dbg in (256, 512, 512 | (1 << 26), 0, 524288):          # float64 rows, 16-bit filter + refine (16- and 8-wave workgroups), library's choice, all layouts
                 fv.set_option(decoder.OPT_DEBUG, dbg)
                 path, score, rc = fv.decode_beam(ob, N, B)
                 assert path.tolist() == opath.tolist() and score == oscore and rc == orc, (N, dbg)

@@ -77,9 +77,10 @@ def test_beam_memory_resident_select_matches_golden(ctxs, g, r):
 @pytest.mark.parametrize("g,r", PAIRS, ids=IDS)
 def test_beam_q16_filter_kernel_matches_golden(ctxs, g, r):
     """FV_OPT_DEBUG bit 9 forces beam_step_q16 (filter on the 16-bit table + float64 refine), which the
-    library otherwise uses for large launches only; bit 8 forces the float64 kernel."""
+    library otherwise uses for large launches only (bit 26: in its 8-wave workgroup form, otherwise taken by launches with
+    more workgroups than the chip holds at once; bit 25: never); bit 8 forces the float64 kernel."""
     fv, ob = ctxs(g)
-    for dbg in (512, 256):
+    for dbg in (512, 512 | (1 << 26), 512 | (1 << 25), 256):
         fv.set_option(decoder.OPT_DEBUG, dbg)
         try:
             path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
@@ -167,7 +168,7 @@ def test_beam_tie_heavy_models_match_oracle(kind, K, M, T, N, B, seed):
     opath, oscore, _, orc = om.beam_decode(ob, N, B)
     fv = decoder.FlashViterbi(0)
     fv.set_model(A, Bm, Pi)
-    for dbg in (0, 512, 524288, EAGER, EAGER | 512, MANY, MANY | 1024, NOCUT, NOCUT | 512):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
+    for dbg in (0, 512, 524288, EAGER, EAGER | 512, MANY, MANY | 1024, NOCUT, NOCUT | 512, 512 | (1 << 26)):    # bit 19: the layouts of every step and the tie fix-up run unconditionally
         fv.set_option(decoder.OPT_DEBUG, dbg)
         path, score, rc = fv.decode_beam(ob, N, B)
         assert path.tolist() == opath.tolist() and score == oscore and rc == orc

@@ -126,14 +126,14 @@ def test_no_accepted_option_value_changes_a_result():
     fv.set_model(A, B, Pi)
     try:
         accepted = 0
-        for bit in range(25):
+        for bit in range(27):
             v = 1 << bit
             if v & decoder.DEBUG_TIMING_ONLY:
                 with pytest.raises(decoder.FlashVitError):
                     fv.set_option(decoder.OPT_DEBUG, v)
                 continue
             accepted |= v
-        for v in [1 << b for b in range(25) if (1 << b) & accepted] + [accepted, accepted & ~(256 | 65536), 0]:
+        for v in [1 << b for b in range(27) if (1 << b) & accepted] + [accepted, accepted & ~(256 | 65536), accepted & ~(1 << 25), 0]:
             fv.set_option(decoder.OPT_DEBUG, v)
             for kernel in (decoder.KERNEL_AUTO, decoder.KERNEL_U16_REFINE, decoder.KERNEL_Q16_REFINE, decoder.KERNEL_SPARSE_Q16):
                 fv.set_option(decoder.OPT_KERNEL, kernel)
@@ -149,7 +149,7 @@ def test_no_accepted_option_value_changes_a_result():
                 assert rc == 0 and path.tolist() == full["path"]
                 path, score, rc = fv.decode_beam(ob, 8, beam["B"])
                 assert path.tolist() == beam["path"]
-        for key, bad in ((decoder.OPT_DEBUG, -1), (decoder.OPT_DEBUG, 1 << 25), (decoder.OPT_KERNEL, 7), (decoder.OPT_MAX_BATCH, 9), (99, 0)):
+        for key, bad in ((decoder.OPT_DEBUG, -1), (decoder.OPT_DEBUG, 1 << 27), (decoder.OPT_KERNEL, 7), (decoder.OPT_MAX_BATCH, 9), (99, 0)):
             with pytest.raises(decoder.FlashVitError):
                 fv.set_option(key, bad)
     finally:

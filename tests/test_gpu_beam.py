@@ -223,6 +223,29 @@ def test_beam_candidate_lists_under_ties_and_bad_predictions(kind, K, M, T, N, B
     assert kind != "data_script" or used > 0          # the generate_data model does use its lists
 
 
+def test_beam_long_sequence_with_chains_of_undecided_steps_equals_oracle():
+    """T = 1500 at K = 20000: scores near -17000 have float spacings of 2e-3, most cuts fall on duplicated values, runs of
+    undecided steps form, and ~70 selections find a doubtful column inside their beam.  The resolve code then decides the run
+    only back to a step whose replay provably ignores its doubtful columns (replay_safe; FV_OPT_DEBUG bit 23: the whole run):
+    fewer exact replays, the same bits."""
+    import modelgen
+    spec = dict(kind="sparse_fast", K=20000, M=8, T=1500, prob=0.05, seed=77)
+    A, Bm, Pi, ob = modelgen.model32(spec)
+    om = oracle.OracleModel(A, Bm, Pi)
+    opath, oscore, _, orc = om.beam_decode(ob, 4, 400)
+    fv = decoder.FlashViterbi(0)
+    fv.set_model(A, Bm, Pi)
+    seen = {}
+    for dbg in (0, NOCUT, 512):
+        fv.set_option(decoder.OPT_DEBUG, dbg)
+        path, score, rc = fv.decode_beam(ob, 4, 400)
+        assert path.tolist() == opath.tolist() and score == oscore and rc == orc, dbg
+        st = fv.stats()
+        seen[dbg] = (st["beam_chain_cuts"], st["beam_exact_sets"], st["beam_reach_events"])
+    fv.close()
+    assert seen[0][0] > 0 and seen[NOCUT][0] == 0 and seen[0][1] < seen[NOCUT][1] and seen[0][2] > 0, seen
+
+
 def test_beam_equal_to_K_is_full_decode():
     """B = K keeps every state: same path and score as the full-state decoder."""
     import modelgen

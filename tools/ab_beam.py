@@ -1,11 +1,13 @@
 """A/B timing of FLASH-BS under several FV_OPT_DEBUG values on BASELINE cfg4 / cfg5 (same context, same model, paths compared).
-   python tools/ab_beam.py cfg4|cfg5  dbg [dbg ...]        (first value = the reference run; 0 = library default)"""
+   python tools/ab_beam.py cfg2b32|cfg2b256|cfg4|cfg5  dbg [dbg ...]        (first value = the reference run; 0 = library default)"""
 import os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import modelgen
 from flash_viterbi_amd import decoder
-CFG = {"cfg4": (dict(kind="data_script", K=16384, M=50, T=256, prob=0.112, seed=12), 8, 256, 7),
+CFG = {"cfg2b32": (dict(kind="data_script", K=3965, M=50, T=256, prob=0.112, seed=12), 8, 32, 9),      # the reference driver's own parameter set (src/run.py)
+       "cfg2b256": (dict(kind="data_script", K=3965, M=50, T=256, prob=0.112, seed=12), 8, 256, 9),
+       "cfg4": (dict(kind="data_script", K=16384, M=50, T=256, prob=0.112, seed=12), 8, 256, 7),
        "cfg5": (dict(kind="sparse_fast", K=65536, M=50, T=1024, prob=0.112, seed=12), 8, 1024, 3)}
 spec, N, B, reps = CFG[sys.argv[1]]
 t0 = time.time()

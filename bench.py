@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 M_SYMBOLS, PROB, SEED, N_SPLIT = 50, 0.112, 12, 8
 
 WORKLOADS = {
-    "cfg2": dict(kind="full", K=3965, T=256, beam=0, gen="data_script", steps=20, warmup=3, label="BASELINE configs[1]"),
+    "cfg2": dict(kind="full", K=3965, T=256, beam=0, gen="data_script", steps=50, warmup=5, label="BASELINE configs[1]"),
     "cfg3": dict(kind="full", K=3965, T=4096, beam=0, gen="data_script", steps=5, warmup=1, label="BASELINE configs[2]"),
     "cfg4": dict(kind="beam", K=16384, T=256, beam=256, gen="data_script", steps=10, warmup=2, label="BASELINE configs[3]"),
     "cfg5": dict(kind="beam", K=65536, T=1024, beam=1024, gen="fast", steps=3, warmup=1, label="BASELINE configs[4]"),

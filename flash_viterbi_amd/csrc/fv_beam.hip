@@ -136,8 +136,11 @@ int run_generation_beam(fv_ctx *ctx, const std::vector<fv::Pass> &passes, size_t
                 else if (use_q16)
                     hipLaunchKernelGGL(fvb::beam_step_q16<16>, dim3(panels, a.n), dim3(fvb::BEAM_BLOCK),
                                        fvb::beam_step_q16_lds(beam), st, a);
+                // (small beams: four waves per workgroup — K = 3965, B = 32: 4.55 -> 4.23 ms; eight waves at B = 256: 6.43 -> 6.50, not kept)
+                else if (beam <= 64 && !(ctx->opt_debug & (1 << 25)))
+                    hipLaunchKernelGGL(fvb::beam_step<4>, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(4 * 64), fvb::beam_step_lds(beam, 4), st, a);
                 else
-                    hipLaunchKernelGGL(fvb::beam_step, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
+                    hipLaunchKernelGGL(fvb::beam_step<16>, dim3(beam_ld(K) / fvb::BEAM_COLS, a.n), dim3(fvb::BEAM_BLOCK), fvb::beam_step_lds(beam),
                                        st, a);
                 FV_HIP(hipGetLastError());
                 ctx->stats.step_launches += 1;

@@ -76,7 +76,8 @@ enum {
                                layout rebuilt and every tie re-decided whether or not the path needs it, 20 every duplicate
                                step replays its heap at once (no speculative member lists), 22 every selection in the memory-resident
                                form (the route of K > 65536), 23 runs of undecided steps always decided in full, 24 four-wave select also on steps that may have to be resolved,
-                               25 / 26 the 16-bit step kernel in 16-wave / 8-wave workgroups whatever the launch size */
+                               25 / 26 the 16-bit step kernel in 16-wave / 8-wave workgroups whatever the launch size (25 also: the float64
+                               step kernel in 16-wave workgroups for small beams too) */
 };
 #define FV_DEBUG_TIMING_ONLY ((1 << 0) | (1 << 4) | (1 << 5) | (1 << 11) | (1 << 12))
 enum {

@@ -80,7 +80,7 @@ def test_beam_q16_filter_kernel_matches_golden(ctxs, g, r):
     library otherwise uses for large launches only (bit 26: in its 8-wave workgroup form, otherwise taken by launches with
     more workgroups than the chip holds at once; bit 25: never); bit 8 forces the float64 kernel."""
     fv, ob = ctxs(g)
-    for dbg in (512, 512 | (1 << 26), 512 | (1 << 25), 256):
+    for dbg in (512, 512 | (1 << 26), 512 | (1 << 25), 256, 256 | (1 << 25)):     # (256: beams up to 64 run four-wave workgroups, with bit 25 sixteen)
         fv.set_option(decoder.OPT_DEBUG, dbg)
         try:
             path, score, rc = fv.decode_beam(ob, r["N"], r["B"], decoder.MODE_REFERENCE)
